@@ -1,0 +1,167 @@
+/* pixpro_hip.h — C ABI of libpixpro_hip.so (MI355X / gfx950).
+ *
+ * The reference (rioyokotalab/PixPro-with-OpticalFlow) is pure Python/PyTorch and has no
+ * native ABI of its own; every entry point below replaces the chain of stock torch kernels
+ * that one reference *function* launches, and cites that function (file:line relative to
+ * the reference root).  The Python host in pixpro-with-opticalflow_amd/contrast/ binds
+ * these with ctypes (see INTEGRATION.md for the stub a maintainer would add).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to a contiguous fp32 (or uint8 for masks) array,
+ *     unless the parameter name ends in _host;
+ *   - the caller owns all memory, including workspaces (query *_workspace_bytes first);
+ *     the library never allocates, frees or synchronises;
+ *   - kernels are enqueued on `stream` (a hipStream_t passed as void*; NULL = default);
+ *   - return value 0 = success; otherwise an error code, text via pixpro_last_error()
+ *     (thread-local).  Functions are re-entrant.
+ */
+#ifndef PIXPRO_HIP_H
+#define PIXPRO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PIXPRO_OK 0
+#define PIXPRO_ERR_ARG 1      /* bad shape / null pointer / unsupported combination */
+#define PIXPRO_ERR_WORKSPACE 2 /* workspace too small */
+#define PIXPRO_ERR_LAUNCH 3   /* hipLaunch failure (text carries hipGetErrorString) */
+
+#define PIXPRO_MAX_DIRS 2
+
+/* Geometry + hyper-parameters of one PPM/loss problem.
+ * N samples, C channels, H x W feature grid (P = H*W), flow map Hf x Wf (0 = no flow),
+ * original frame Ho x Wo (used only when size_dev == NULL and Ho > 0; when both are
+ * absent the frame size is read on the device from coord_q[0][9], coord_q[0][8] exactly as
+ * contrast/models/PixPro.py:124 does on the host). */
+typedef struct pixpro_problem {
+  int32_t N, C, H, W;
+  int32_t Hf, Wf;
+  int32_t Ho, Wo;
+  float p;          /* --pixpro-p            (PixPro.py:358) */
+  float clamp;      /* --pixpro-clamp-value  (PixPro.py:355) */
+  float pos_ratio;  /* --pixpro-pos-ratio    (PixPro.py:219) */
+  int32_t normalize_k; /* 1: k is the raw projector_k output, L2-normalise it over C inside
+                          (PixPro.py:403,407); 0: k is already unit-norm */
+  int32_t ndir;     /* 1 or 2 loss directions handled by one call */
+  float grad_scale; /* upstream d(loss): grads are those of grad_scale * loss (normally 1) */
+} pixpro_problem;
+
+/* Per-direction operands.  Direction d: q-side view (x,v), k-side momentum projection k.
+ * mask: uint8 [N,Hf,Wf] (torch.bool storage) or NULL.  flow: [N,2,Hf,Wf] or NULL.
+ * size_dev: int32[2] = {Ho, Wo} on the device or NULL.
+ * Outputs: pred [N,C,P] = normalize(featprop(x)) (nullable); dx, dv [N,C,P] (nullable, both
+ * or neither). */
+typedef struct pixpro_dir {
+  const float* x;
+  const float* v;
+  const float* k;
+  const float* coord_q;   /* [N,10] */
+  const float* coord_k;   /* [N,10] */
+  const float* flow;
+  const uint8_t* mask;
+  const int32_t* size_dev;
+  float* pred;
+  float* dx;
+  float* dv;
+} pixpro_dir;
+
+int pixpro_version(void);
+const char* pixpro_last_error(void);
+
+/* ---- K1+K2+K3+K4 fused: PixPro.featprop (PixPro.py:339-363) + F.normalize (:380) +
+ * regression_loss (:92-247, incl. add_optical_flow :46-89) and their backward.
+ * loss_n, pos_num, pos_mean: [ndir*N]; loss: [1] = sum over directions of -2*mean_n(loss_n)
+ * (PixPro.py:247,431).  Gradients (if dx != NULL) are d(grad_scale*loss)/dx, /dv.
+ * Uses the single-launch MFMA kernel when P<=64 and C%128==0 (C<=256), otherwise the
+ * staged generic path (needs workspace). */
+size_t pixpro_ppm_loss_workspace_bytes(const pixpro_problem* pb);
+int pixpro_ppm_loss(const pixpro_problem* pb, const pixpro_dir* dirs, float* loss_n,
+                    float* pos_num, float* pos_mean, float* loss, void* workspace,
+                    size_t workspace_bytes, void* stream);
+/* Same, forcing the staged generic path (used by tests as an on-device cross-check). */
+int pixpro_ppm_loss_generic(const pixpro_problem* pb, const pixpro_dir* dirs, float* loss_n,
+                            float* pos_num, float* pos_mean, float* loss, void* workspace,
+                            size_t workspace_bytes, void* stream);
+
+/* buf[i] *= *scale_dev for i < n; returns immediately on the device when *scale_dev == 1.
+ * Lets autograd apply a non-unit upstream gradient to the saved dx/dv without a host sync. */
+int pixpro_scale_by_device_scalar(float* buf, size_t n, const float* scale_dev, void* stream);
+
+/* ---- PixPro.featprop alone (public method, PixPro.py:339-363): Y = v_hat * A^T.
+ * x, v, Y, dY, dx, dv: [N,C,P].  pb->N,C,H,W,p,clamp are used. */
+size_t pixpro_featprop_workspace_bytes(const pixpro_problem* pb);
+int pixpro_featprop_fwd(const pixpro_problem* pb, const float* x, const float* v, float* Y,
+                        void* workspace, size_t workspace_bytes, void* stream);
+int pixpro_featprop_bwd(const pixpro_problem* pb, const float* x, const float* v,
+                        const float* dY, float* dx, float* dv, void* workspace,
+                        size_t workspace_bytes, void* stream);
+
+/* ---- regression_loss alone (module function, PixPro.py:92-247): q (differentiable) and k
+ * are given as-is ([N,C,P]); d->x = q, d->k = k, d->dx = dq (nullable); d->v, d->pred,
+ * d->dv ignored.  loss = -2*mean_n(loss_n). */
+size_t pixpro_regression_loss_workspace_bytes(const pixpro_problem* pb);
+int pixpro_regression_loss(const pixpro_problem* pb, const pixpro_dir* d, float* loss_n,
+                           float* pos_num, float* pos_mean, float* loss, void* workspace,
+                           size_t workspace_bytes, void* stream);
+
+/* ---- add_optical_flow (PixPro.py:46-89): x_grid, y_grid, out_x, out_y [N,H,W];
+ * mask_grid uint8 [N,H,W] (nullable iff mask NULL).  Needs pb->N,H,W,Hf,Wf,Ho,Wo. */
+int pixpro_add_optical_flow(const pixpro_problem* pb, const float* flow, const float* x_grid,
+                            const float* y_grid, const uint8_t* mask, float* out_x,
+                            float* out_y, uint8_t* mask_grid, void* stream);
+
+/* ---- flow preparation (contrast/util.py) ------------------------------------------- */
+/* upflow8 (contrast/flow/utils/utils.py:87-89): in [M,h,w] planes -> out [M,8h,8w],
+ * 8 * bilinear(align_corners=True). */
+int pixpro_upflow8(const float* in, float* out, int64_t planes, int32_t h, int32_t w,
+                   void* stream);
+/* concat_flow (util.py:300-330): flows [F1,N,2,Hf,Wf] -> out [N,2,Hf,Wf]; is_norm as in the
+ * reference (--flow_cat_norm). */
+int pixpro_concat_flow(const float* flows, float* out, int32_t F1, int32_t N, int32_t Hf,
+                       int32_t Wf, int32_t is_norm, void* stream);
+/* forward_backward_consistency (util.py:252-297): mask uint8 [N,Hf,Wf] (1 = valid);
+ * cycle [N,2,Hf,Wf] nullable (debug output of the reference). */
+int pixpro_fbc_mask(const float* flow_fwd, const float* flow_bwd, uint8_t* mask, float* cycle,
+                    int32_t N, int32_t Hf, int32_t Wf, float alpha1, double alpha2,
+                    int32_t is_norm, void* stream);
+/* Fused file-mode apply_optical_flow (util.py:174-248, use_flow_frames=False,
+ * flow_cat_norm=False): low-res flows lo_fwd/lo_bwd [N,F1,2,h,w] (loader layout, before the
+ * permute of util.py:183) -> composed flows [N,2,Hf,Wf] and masks uint8 [N,Hf,Wf]
+ * (Hf,Wf = 8h,8w if flow_up else h,w).  masks nullable (alpha None).  invalid_count
+ * (nullable) int32 [2*N]: number of invalid pixels per sample (fwd then bwd), the numerator
+ * of calc_mask_ratio (util.py:360-366).  F1 == 1 (nframe 2): ONE launch, the only HBM
+ * traffic is the low-res read and the output write; F1 > 1: one chain launch (up-sampling
+ * evaluated lazily) + two mask launches.  No workspace. */
+int pixpro_flow_prepare(const float* lo_fwd, const float* lo_bwd, float* flow_fwd,
+                        float* flow_bwd, uint8_t* mask_fwd, uint8_t* mask_bwd,
+                        int32_t* invalid_count, int32_t N, int32_t F1, int32_t h, int32_t w,
+                        int32_t flow_up, float alpha1, double alpha2, void* stream);
+/* calc_mask_ratio (util.py:360-366): ratio[n] = mean(!mask[n]). */
+int pixpro_mask_ratio(const uint8_t* mask, float* ratio, int32_t N, int64_t pixels,
+                      void* stream);
+
+/* ---- multi-tensor updates around the path ("next" rows of SURVEY.md §8f) ------------- */
+/* Momentum (EMA) update, PixPro.py:321-337: pk = pk*m + pq*(1-m) for `count` tensors.
+ * pq_ptrs / pk_ptrs / sizes: DEVICE arrays of count pointers / element counts; m is the
+ * python double of PixPro.py:326 (the kernel uses fl32(m) and fl32(1-m) like the reference). */
+int pixpro_ema_update(const float* const* pq_ptrs, float* const* pk_ptrs,
+                      const int64_t* sizes, int32_t count, double m, void* stream);
+/* LARS + SGD-momentum step without host syncs (contrast/lars.py:109-151 followed by
+ * torch.optim.SGD with momentum, dampening 0, no nesterov).  Per tensor t:
+ *   g = grad + wd[t]*p;  if adapt[t] and |p|>0 and |g|>0: g *= trust*|p|/(|g|+eps)
+ *   buf = first_step ? g : momentum*buf + g;  p -= lr*buf.
+ * norms2: DEVICE scratch float[2*count] (zeroed by the call). */
+int pixpro_lars_sgd_step(float* const* p_ptrs, const float* const* g_ptrs,
+                         float* const* buf_ptrs, const int64_t* sizes, const float* wd,
+                         const int32_t* adapt, int32_t count, float lr, float momentum,
+                         float trust_coef, float eps, int32_t first_step, float* norms2,
+                         void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PIXPRO_HIP_H */

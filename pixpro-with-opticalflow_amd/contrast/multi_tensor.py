@@ -1,0 +1,76 @@
+"""Multi-tensor HIP updates (one launch over a device-side pointer table).
+
+`ema_update`     momentum update of the key encoder           <- PixPro.py:321-337
+`LarsSgdStep`    LARS scaling + SGD-momentum step, sync-free   <- contrast/lars.py:109-151
+"""
+import torch
+
+from . import _native as nv
+
+
+class _Table:
+    """Device arrays of pointers / sizes for a list of tensors; rebuilt only when a pointer moves."""
+
+    def __init__(self):
+        self.key = None
+        self.dev = None
+
+    def get(self, groups, device):
+        key = tuple(t.data_ptr() for g in groups for t in g)
+        if key != self.key:
+            n = len(groups[0])
+            host = torch.tensor([[t.data_ptr() for t in g] for g in groups] + [[t.numel() for t in groups[0]]],
+                                dtype=torch.int64)
+            self.dev = host.to(device)
+            self.key = key
+            self.n = n
+        return self.dev
+
+
+_ema_table = _Table()
+
+
+def _check(ts, what):
+    for t in ts:
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise RuntimeError(f"{what}: needs contiguous fp32 CUDA tensors (no CPU fallback)")
+
+
+@torch.no_grad()
+def ema_update(params_q, params_k, m):
+    """param_k <- param_k * m + param_q * (1 - m) for every pair, one launch."""
+    pq = [p.data for p in params_q]
+    pk = [p.data for p in params_k]
+    _check(pq + pk, "ema_update")
+    tab = _ema_table.get([pq, pk], pq[0].device)
+    nv.call("pixpro_ema_update", nv.ptr(tab[0]), nv.ptr(tab[1]), nv.ptr(tab[2]), len(pq), float(m), nv.stream())
+
+
+class LarsSgdStep:
+    """Fused step for a fixed list of parameters.  wd/adapt per tensor as contrast/lars.py groups them
+    (1-D params: no decay, no adaptation)."""
+
+    def __init__(self, params, weight_decays, adapts, momentum, trust_coef=0.001, eps=1e-8):
+        self.params = list(params)
+        self.momentum, self.trust, self.eps = momentum, trust_coef, eps
+        dev = self.params[0].device
+        _check([p.data for p in self.params], "LarsSgdStep")
+        self.bufs = [torch.zeros_like(p.data) for p in self.params]
+        self.wd = torch.tensor(weight_decays, dtype=torch.float32, device=dev)
+        self.adapt = torch.tensor([int(a) for a in adapts], dtype=torch.int32, device=dev)
+        self.norms2 = torch.zeros(2 * len(self.params), dtype=torch.float32, device=dev)
+        self.table = _Table()
+        self.first = True
+
+    @torch.no_grad()
+    def step(self, lr):
+        grads = []
+        for p in self.params:
+            if p.grad is None:
+                raise RuntimeError("LarsSgdStep: every parameter needs a gradient")
+            grads.append(p.grad if p.grad.is_contiguous() else p.grad.contiguous())
+        tab = self.table.get([[p.data for p in self.params], grads, self.bufs], self.params[0].device)
+        nv.call("pixpro_lars_sgd_step", nv.ptr(tab[0]), nv.ptr(tab[1]), nv.ptr(tab[2]), nv.ptr(tab[3]),
+                nv.ptr(self.wd), nv.ptr(self.adapt), len(self.params), float(lr), float(self.momentum),
+                float(self.trust), float(self.eps), int(self.first), nv.ptr(self.norms2), nv.stream())
+        self.first = False

@@ -1,0 +1,231 @@
+"""torch.autograd bindings of the HIP hot path.
+
+`ppm_loss`        fused featprop + normalize + regression_loss (both loss directions, fwd+bwd,
+                  one launch)                      <- PixPro.forward, PixPro.py:376-385,429-431
+`featprop`        PixPro.featprop alone           <- PixPro.py:339-363
+`regression_loss` module-level loss alone         <- PixPro.py:92-247
+`add_optical_flow`                                 <- PixPro.py:46-89
+
+Everything here needs CUDA tensors and the built shared library; nothing falls back to torch ops.
+"""
+import ctypes
+
+import torch
+
+from . import _native as nv
+
+
+def _size_fields(size, flow, device):
+    """(Ho, Wo, size_dev_tensor).  size: None | (Ho, Wo) | Tensor[2].  A device tensor is handed to the
+    kernel as-is (no .item() sync, unlike PixPro.py:116); a host tensor / tuple is read here."""
+    if size is None:
+        if flow is not None:
+            return int(flow.shape[-2]), int(flow.shape[-1]), None
+        return 0, 0, None
+    if isinstance(size, torch.Tensor):
+        if size.is_cuda:
+            return 0, 0, size.reshape(-1)[:2].to(torch.int32).contiguous()
+        return int(size[0].item()), int(size[1].item()), None
+    return int(size[0]), int(size[1]), None
+
+
+class Direction:
+    """Operands of one loss direction (q-side features x/v, k-side momentum projection k)."""
+
+    def __init__(self, x, v, k, coord_q, coord_k, flow=None, mask=None, size=None):
+        self.x, self.v, self.k = x, v, k
+        self.coord_q, self.coord_k = coord_q, coord_k
+        self.flow, self.mask, self.size = flow, mask, size
+
+
+def _problem(dirs, p, clamp, pos_ratio, normalize_k, grad_scale=1.0):
+    d0 = dirs[0]
+    N, C, H, W = d0.x.shape
+    pb = nv.Problem()
+    pb.N, pb.C, pb.H, pb.W = N, C, H, W
+    pb.p, pb.clamp, pb.pos_ratio = float(p), float(clamp), float(pos_ratio)
+    pb.normalize_k, pb.ndir, pb.grad_scale = int(bool(normalize_k)), len(dirs), float(grad_scale)
+    keep = []
+    cds = (nv.Dir * 2)()
+    for i, d in enumerate(dirs):
+        shape = (N, C, H, W)
+        x = nv.dev_f32(d.x, "x", shape)
+        v = nv.dev_f32(d.v, "v", shape) if d.v is not None else None
+        k = nv.dev_f32(d.k, "k", shape)
+        cq = nv.dev_f32(d.coord_q, "coord_q", (N, 10))
+        ck = nv.dev_f32(d.coord_k, "coord_k", (N, 10))
+        flow = mask = None
+        if d.flow is not None:
+            if d.flow.dim() != 4 or d.flow.shape[0] != N or d.flow.shape[1] != 2:
+                raise RuntimeError(f"flow: expected [N,2,Hf,Wf] with N={N}, got {tuple(d.flow.shape)}")
+            flow = nv.dev_f32(d.flow, "flow")
+            Hf, Wf = int(flow.shape[-2]), int(flow.shape[-1])
+            if i and (Hf, Wf) != (pb.Hf, pb.Wf):
+                raise RuntimeError("both directions must use the same flow map size")
+            pb.Hf, pb.Wf = Hf, Wf
+            if d.mask is not None:
+                mask = nv.dev_mask(d.mask, "mask", (N, Hf, Wf))
+        elif d.mask is not None:
+            raise RuntimeError("mask given without flow")
+        Ho, Wo, size_dev = _size_fields(d.size, flow, x.device)
+        if i and (Ho, Wo) != (pb.Ho, pb.Wo):
+            raise RuntimeError("both directions must use the same frame size")
+        pb.Ho, pb.Wo = Ho, Wo
+        keep += [x, v, k, cq, ck, flow, mask, size_dev]
+        c = cds[i]
+        c.x, c.v, c.k = nv.ptr(x), nv.ptr(v), nv.ptr(k)
+        c.coord_q, c.coord_k = nv.ptr(cq), nv.ptr(ck)
+        c.flow, c.mask, c.size_dev = nv.ptr(flow), nv.ptr(mask), nv.ptr(size_dev)
+    return pb, cds, keep
+
+
+class _PPMLoss(torch.autograd.Function):
+    """inputs: x_0, v_0, [x_1, v_1]; everything else (k, coords, flows, masks) is constant."""
+
+    @staticmethod
+    def forward(ctx, meta, *xv):
+        dirs, p, clamp, pos_ratio, normalize_k, want_pred, generic = meta
+        nd = len(dirs)
+        for i, d in enumerate(dirs):
+            d.x, d.v = xv[2 * i], xv[2 * i + 1]
+        pb, cds, keep = _problem(dirs, p, clamp, pos_ratio, normalize_k)
+        x0 = keep[0]
+        dev = x0.device
+        N = pb.N
+        want_grad = any(ctx.needs_input_grad[1:])
+        out = torch.empty(3 * nd * N + 1, dtype=torch.float32, device=dev)
+        loss_n, pos_num, pos_mean = out[:nd * N], out[nd * N:2 * nd * N], out[2 * nd * N:3 * nd * N]
+        loss = out[3 * nd * N:]
+        grads = torch.empty((2 * nd,) + tuple(x0.shape), dtype=torch.float32, device=dev) if want_grad else None
+        preds = torch.empty((nd,) + tuple(x0.shape), dtype=torch.float32, device=dev) if want_pred else None
+        for i in range(nd):
+            if want_grad:
+                cds[i].dx, cds[i].dv = nv.ptr(grads[2 * i]), nv.ptr(grads[2 * i + 1])
+            if want_pred:
+                cds[i].pred = nv.ptr(preds[i])
+        lib = nv.load()
+        ws_bytes = lib.pixpro_ppm_loss_workspace_bytes(ctypes.byref(pb))
+        fused = (not generic) and pb.H * pb.W <= 64 and pb.C in (128, 256)
+        ws = None if fused else nv.workspace(ws_bytes, dev)
+        nv.call("pixpro_ppm_loss_generic" if generic else "pixpro_ppm_loss", ctypes.byref(pb), cds,
+                nv.ptr(loss_n), nv.ptr(pos_num), nv.ptr(pos_mean), nv.ptr(loss), nv.ptr(ws),
+                0 if ws is None else ws.numel(), nv.stream())
+        ctx.grads = grads
+        ctx.nd = nd
+        loss_s = loss.reshape(())
+        outs = [loss_s, pos_num.reshape(nd, N), pos_mean.reshape(nd, N), loss_n.reshape(nd, N)]
+        ctx.mark_non_differentiable(*outs[1:])
+        if want_pred:
+            ctx.mark_non_differentiable(preds)
+            outs.append(preds)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, gloss, *_):
+        grads = ctx.grads
+        if grads is None:
+            return (None,) * (1 + 2 * ctx.nd)
+        # grads hold applied * d(loss)/d(x,v); bring them to the upstream scalar on the device (the kernel
+        # returns at once when the ratio is 1, the usual case) - no host sync, safe under retain_graph
+        g = gloss.detach().to(torch.float32).reshape(1)
+        applied = getattr(ctx, "applied", None)
+        ratio = (g if applied is None else g / applied).contiguous()
+        nv.call("pixpro_scale_by_device_scalar", nv.ptr(grads), grads.numel(), nv.ptr(ratio), nv.stream())
+        ctx.applied = g.clone()
+        return (None,) + tuple(grads[i] for i in range(2 * ctx.nd))
+
+
+def ppm_loss(dirs, p, clamp, pos_ratio, normalize_k=True, want_pred=False, generic=False):
+    """dirs: list of 1 or 2 `Direction`.  Returns (loss, pos_num[nd,N], pos_mean[nd,N], loss_n[nd,N]
+    [, preds[nd,N,C,H,W]]).  loss is differentiable w.r.t. every x and v."""
+    xv = []
+    for d in dirs:
+        xv += [d.x, d.v]
+    return _PPMLoss.apply((dirs, p, clamp, pos_ratio, normalize_k, want_pred, generic), *xv)
+
+
+class _FeatProp(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, v, p, clamp):
+        N, C, H, W = x.shape
+        x = nv.dev_f32(x, "feat")
+        v = nv.dev_f32(v, "value", x.shape)
+        pb = nv.Problem()
+        pb.N, pb.C, pb.H, pb.W, pb.p, pb.clamp, pb.ndir = N, C, H, W, float(p), float(clamp), 1
+        Y = torch.empty_like(x)
+        lib = nv.load()
+        ws = nv.workspace(lib.pixpro_featprop_workspace_bytes(ctypes.byref(pb)), x.device)
+        nv.call("pixpro_featprop_fwd", ctypes.byref(pb), nv.ptr(x), nv.ptr(v), nv.ptr(Y), nv.ptr(ws), ws.numel(),
+                nv.stream())
+        ctx.save_for_backward(x, v)
+        ctx.pc = (float(p), float(clamp))
+        return Y
+
+    @staticmethod
+    def backward(ctx, dY):
+        x, v = ctx.saved_tensors
+        N, C, H, W = x.shape
+        pb = nv.Problem()
+        pb.N, pb.C, pb.H, pb.W, pb.p, pb.clamp, pb.ndir = N, C, H, W, ctx.pc[0], ctx.pc[1], 1
+        dY = nv.dev_f32(dY, "dY", x.shape)
+        dx, dv = torch.empty_like(x), torch.empty_like(x)
+        lib = nv.load()
+        ws = nv.workspace(lib.pixpro_featprop_workspace_bytes(ctypes.byref(pb)), x.device)
+        nv.call("pixpro_featprop_bwd", ctypes.byref(pb), nv.ptr(x), nv.ptr(v), nv.ptr(dY), nv.ptr(dx), nv.ptr(dv),
+                nv.ptr(ws), ws.numel(), nv.stream())
+        return dx, dv, None, None
+
+
+def featprop(x, v, p, clamp):
+    """Y = normalize(v) @ (clamp(normalize(x)^T normalize(x)) ** p)^T    (PixPro.py:339-363)."""
+    return _FeatProp.apply(x, v, p, clamp)
+
+
+class _RegLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, meta):
+        d, pos_ratio = meta
+        d.x, d.v = q, None
+        pb, cds, keep = _problem([d], 1.0, 0.0, pos_ratio, False)
+        dev = keep[0].device
+        N = pb.N
+        out = torch.empty(3 * N + 1, dtype=torch.float32, device=dev)
+        dq = torch.empty_like(keep[0]) if ctx.needs_input_grad[0] else None
+        cds[0].dx = nv.ptr(dq)
+        lib = nv.load()
+        ws = nv.workspace(lib.pixpro_regression_loss_workspace_bytes(ctypes.byref(pb)), dev)
+        nv.call("pixpro_regression_loss", ctypes.byref(pb), cds, nv.ptr(out[:N]), nv.ptr(out[N:2 * N]),
+                nv.ptr(out[2 * N:3 * N]), nv.ptr(out[3 * N:]), nv.ptr(ws), ws.numel(), nv.stream())
+        ctx.dq = dq
+        pos_num, pos_mean = out[N:2 * N], out[2 * N:3 * N]
+        ctx.mark_non_differentiable(pos_num, pos_mean)
+        return out[3 * N:].reshape(()), pos_num, pos_mean
+
+    @staticmethod
+    def backward(ctx, gloss, *_):
+        if ctx.dq is None:
+            return None, None
+        return ctx.dq * gloss, None
+
+
+def regression_loss_op(q, k, coord_q, coord_k, pos_ratio, flow=None, mask=None, size=None):
+    d = Direction(q, None, k, coord_q, coord_k, flow, mask, size)
+    return _RegLoss.apply(q, (d, pos_ratio))
+
+
+def add_optical_flow_op(flow, x_grid, y_grid, size, mask=None):
+    N, H, W = x_grid.shape
+    flow = nv.dev_f32(flow, "flow")
+    Hf, Wf = int(flow.shape[-2]), int(flow.shape[-1])
+    xg = nv.dev_f32(x_grid, "x_grid")
+    yg = nv.dev_f32(y_grid, "y_grid", xg.shape)
+    pb = nv.Problem()
+    pb.N, pb.C, pb.H, pb.W, pb.Hf, pb.Wf, pb.Ho, pb.Wo, pb.ndir = N, 1, H, W, Hf, Wf, int(size[0]), int(size[1]), 1
+    ox, oy = torch.empty_like(xg), torch.empty_like(yg)
+    mg = None
+    if mask is not None:
+        mask = nv.dev_mask(mask, "mask", (N, Hf, Wf))
+        mg = torch.empty((N, 1, H, W), dtype=torch.bool, device=xg.device)
+    nv.call("pixpro_add_optical_flow", ctypes.byref(pb), nv.ptr(flow), nv.ptr(xg), nv.ptr(yg), nv.ptr(mask),
+            nv.ptr(ox), nv.ptr(oy), nv.ptr(mg), nv.stream())
+    return ox, oy, mg

@@ -1,0 +1,228 @@
+"""`contrast.util` surface: flow preparation on the HIP library + the small training helpers.
+
+Signatures follow the reference's contrast/util.py (apply_optical_flow :175, all_concat_flow :105,
+forward_backward_consistency :253, concat_flow :301, normalize_coord :334, normalize_flow :343,
+denormalize_flow :352, calc_mask_ratio :361, AverageMeter :10, reduce_tensor :64); `upflow8` is the
+reference's contrast/flow/utils/utils.py:87.  `calc_frame_ratio` is called by the reference's
+main_pretrain.py:230 but defined nowhere (defect D1); it is defined here with the contract its caller
+needs.  The online-RAFT branch of apply_optical_flow is out of scope and raises.
+"""
+import argparse
+
+import torch
+import torch.distributed as dist
+
+from . import _native as nv
+
+
+class AverageMeter(object):
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.val = self.avg = self.sum = self.count = 0
+
+    def update(self, val, n=1):
+        self.val = val
+        self.sum += val * n
+        self.count += n
+        self.avg = self.sum / self.count
+
+
+def reduce_tensor(tensor):
+    rt = tensor.clone()
+    dist.all_reduce(rt, op=dist.ReduceOp.SUM)
+    rt /= dist.get_world_size()
+    return rt
+
+
+class MyHelpFormatter(argparse.MetavarTypeHelpFormatter, argparse.ArgumentDefaultsHelpFormatter):
+    pass
+
+
+# ------------------------------------------------------------------------------------------
+# element-wise helpers of the reference API (tiny; stock torch, device-agnostic)
+# ------------------------------------------------------------------------------------------
+@torch.no_grad()
+def normalize_coord(coords):
+    _, _, ht, wd = coords.shape
+    out = coords.clone()
+    out[:, 0] = 2 * out[:, 0] / (wd - 1) - 1
+    out[:, 1] = 2 * out[:, 1] / (ht - 1) - 1
+    return out
+
+
+@torch.no_grad()
+def normalize_flow(flow):
+    _, _, ht, wd = flow.shape
+    out = flow.clone()
+    out[:, 0] = 2 * out[:, 0] / (wd - 1)
+    out[:, 1] = 2 * out[:, 1] / (ht - 1)
+    return out
+
+
+@torch.no_grad()
+def denormalize_flow(flow_norm):
+    _, _, ht, wd = flow_norm.shape
+    out = flow_norm.clone()
+    out[:, 0] = (out[:, 0] * (wd - 1)) / 2
+    out[:, 1] = (out[:, 1] * (ht - 1)) / 2
+    return out
+
+
+# ------------------------------------------------------------------------------------------
+# HIP kernels
+# ------------------------------------------------------------------------------------------
+@torch.no_grad()
+def upflow8(flow, mode='bilinear'):
+    """[M,2,h,w] -> [M,2,8h,8w] = 8 * bilinear(align_corners=True)."""
+    if mode != 'bilinear':
+        raise NotImplementedError("upflow8: only bilinear is used by the pre-training path")
+    flow = nv.dev_f32(flow, "flow")
+    M, C, h, w = flow.shape
+    out = torch.empty((M, C, 8 * h, 8 * w), dtype=torch.float32, device=flow.device)
+    nv.call("pixpro_upflow8", nv.ptr(flow), nv.ptr(out), M * C, h, w, nv.stream())
+    return out
+
+
+@torch.no_grad()
+def concat_flow(flows, is_norm=False):
+    """[F-1,N,2,Hf,Wf] -> composed flow [N,2,Hf,Wf] (one launch; the reference runs F-1 grid_samples)."""
+    flows = nv.dev_f32(flows, "flows")
+    num, nb, two, ht, wd = flows.shape
+    if two != 2:
+        raise RuntimeError(f"flows: expected [F-1,N,2,H,W], got {tuple(flows.shape)}")
+    out = torch.empty((nb, 2, ht, wd), dtype=torch.float32, device=flows.device)
+    nv.call("pixpro_concat_flow", nv.ptr(flows), nv.ptr(out), num, nb, ht, wd, int(bool(is_norm)), nv.stream())
+    return out
+
+
+def all_concat_flow(flow_fwds, flow_bwds, is_norm=False, use_flow_frames=True):
+    if use_flow_frames:
+        raise NotImplementedError("use_flow_frames builds a 5-D flow the loss cannot consume in the "
+                                  "reference either (defect D5); only use_flow_frames=False is supported")
+    return concat_flow(flow_fwds, is_norm), concat_flow(flow_bwds, is_norm)
+
+
+@torch.no_grad()
+def forward_backward_consistency(flow_fwd, flow_bwd, coords0=None, alpha_1=0.01, alpha_2=0.5, is_norm=False):
+    """Returns (coords0_norm, coords1_norm, [mask, flow_cycle]) like the reference; the two coordinate
+    grids are debug outputs there and are returned as None here."""
+    if alpha_1 is None or alpha_2 is None:
+        return flow_fwd.clone(), flow_bwd.clone(), [None, None]
+    f = nv.dev_f32(flow_fwd.detach(), "flow_fwd")
+    b = nv.dev_f32(flow_bwd.detach(), "flow_bwd", f.shape)
+    nb, _, ht, wd = f.shape
+    mask = torch.empty((nb, ht, wd), dtype=torch.bool, device=f.device)
+    cycle = torch.empty_like(f)
+    nv.call("pixpro_fbc_mask", nv.ptr(f), nv.ptr(b), nv.ptr(mask), nv.ptr(cycle), nb, ht, wd, float(alpha_1),
+            float(alpha_2), int(bool(is_norm)), nv.stream())
+    return None, None, [mask, cycle]
+
+
+@torch.no_grad()
+def calc_mask_ratio(mask):
+    if mask is None:
+        return None
+    if isinstance(mask, MaskWithCounts):
+        return mask.invalid_ratio()
+    m = nv.dev_mask(mask, "mask", mask.shape)
+    lead = m.shape[:-2]
+    n = 1
+    for s in lead:
+        n *= s
+    out = torch.empty(n, dtype=torch.float32, device=m.device)
+    nv.call("pixpro_mask_ratio", nv.ptr(m), nv.ptr(out), n, m.shape[-2] * m.shape[-1], nv.stream())
+    return out.reshape(lead)
+
+
+class MaskWithCounts(torch.Tensor):
+    """Bool mask [N,Hf,Wf] that remembers the per-sample invalid-pixel counts produced by the fused
+    flow-prepare launch, so that calc_mask_ratio (logging only) does not re-read the mask from HBM."""
+
+    @staticmethod
+    def wrap(mask, counts):
+        out = mask.as_subclass(MaskWithCounts)
+        out._counts = counts
+        return out
+
+    def invalid_ratio(self):
+        counts = getattr(self, "_counts", None)
+        if counts is None:
+            return calc_mask_ratio(self.as_subclass(torch.Tensor))
+        return counts.to(torch.float32) / float(self.shape[-2] * self.shape[-1])
+
+
+def calc_frame_ratio(cur_n_frames):
+    """Defined for the reference's call site main_pretrain.py:230-231,305,315-337: returns
+    (mean_n_frames, no_optical_flow_ratio, num_per_frame[n,2]) where num_per_frame[i] =
+    (share of samples that used i+1 frames, their count)."""
+    n = cur_n_frames.detach().reshape(-1).to(torch.float32).cpu()
+    total = max(n.numel(), 1)
+    mean_n_frames = float(n.mean()) if n.numel() else 1.0
+    no_of_r = float((n <= 1).float().mean()) if n.numel() else 1.0
+    top = int(n.max()) if n.numel() else 1
+    rows = []
+    for i in range(1, top + 1):
+        c = float((n == i).sum())
+        rows.append([c / total, c])
+    return mean_n_frames, no_of_r, torch.tensor(rows)
+
+
+@torch.no_grad()
+def apply_optical_flow(data, flow_model, args):
+    """File-mode branch of the reference's apply_optical_flow (util.py:174-248), fused:
+    permute + upflow8 + concat_flow (both directions) + the two consistency masks are ONE launch for
+    nframe=2 and three launches for nframe>2, and the up-sampled flows are never materialised.
+    data[5] = [target, flow_fwds[N,F-1,2,h,w], flow_bwds[N,F-1,2,h,w]]; data[6] = [size[N,2], num_img[N,1], ...].
+    Returns [flow_fwd[N,2,Hf,Wf], size, mask_fwd[N,Hf,Wf]], [flow_bwd, size, mask_bwd]."""
+    if not getattr(args, "use_flow_file", True):
+        raise NotImplementedError("online RAFT inference is out of scope; feed flows with --use_flow_file")
+    if getattr(args, "use_flow_frames", False) and data[6][1][0].item() > 2:
+        raise NotImplementedError("use_flow_frames is half-implemented in the reference (defect D5)")
+    if getattr(args, "flow_cat_norm", False):
+        return _apply_optical_flow_staged(data, args)
+    size = data[6][0][0]
+    _, lo_f, lo_b = data[5]
+    lo_f = nv.dev_f32(lo_f, "flow_fwds")
+    lo_b = nv.dev_f32(lo_b, "flow_bwds", lo_f.shape)
+    N, F1, two, h, w = lo_f.shape
+    up = bool(args.flow_up)
+    Hf, Wf = (8 * h, 8 * w) if up else (h, w)
+    dev = lo_f.device
+    flow_fwd = torch.empty((N, 2, Hf, Wf), dtype=torch.float32, device=dev)
+    flow_bwd = torch.empty_like(flow_fwd)
+    is_mask = args.alpha1 is not None and args.alpha2 is not None
+    mask_fwd = mask_bwd = counts = None
+    if is_mask:
+        mask_fwd = torch.empty((N, Hf, Wf), dtype=torch.bool, device=dev)
+        mask_bwd = torch.empty_like(mask_fwd)
+        counts = torch.empty(2 * N, dtype=torch.int32, device=dev)
+    nv.call("pixpro_flow_prepare", nv.ptr(lo_f), nv.ptr(lo_b), nv.ptr(flow_fwd), nv.ptr(flow_bwd),
+            nv.ptr(mask_fwd), nv.ptr(mask_bwd), nv.ptr(counts), N, F1, h, w, int(up),
+            float(args.alpha1) if is_mask else 0.0, float(args.alpha2) if is_mask else 0.0, nv.stream())
+    if is_mask:
+        mask_fwd = MaskWithCounts.wrap(mask_fwd, counts[:N])
+        mask_bwd = MaskWithCounts.wrap(mask_bwd, counts[N:])
+        if getattr(args, "debug", False):
+            mask_fwd, mask_bwd = [mask_fwd, None], [mask_bwd, None]
+    return [flow_fwd, size, mask_fwd], [flow_bwd, size, mask_bwd]
+
+
+def _apply_optical_flow_staged(data, args):
+    """--flow_cat_norm variant (not used by the production recipes): the reference's stage order with
+    one HIP launch per stage."""
+    size = data[6][0][0]
+    _, lo_f, lo_b = data[5]
+    ff = lo_f.permute(1, 0, 2, 3, 4).contiguous()
+    fb = lo_b.permute(1, 0, 2, 3, 4).contiguous()
+    if args.flow_up:
+        num, nb, c, h, w = ff.shape
+        ff = upflow8(ff.reshape(-1, c, h, w)).reshape(num, nb, c, 8 * h, 8 * w)
+        fb = upflow8(fb.reshape(-1, c, h, w)).reshape(num, nb, c, 8 * h, 8 * w)
+    f, b = concat_flow(ff, True), concat_flow(fb, True)
+    mf = mb = None
+    if args.alpha1 is not None and args.alpha2 is not None:
+        mf = forward_backward_consistency(f, b, alpha_1=args.alpha1, alpha_2=args.alpha2, is_norm=True)[2][0]
+        mb = forward_backward_consistency(b, f, alpha_1=args.alpha1, alpha_2=args.alpha2, is_norm=True)[2][0]
+    return [denormalize_flow(f), size, mf], [denormalize_flow(b), size, mb]

@@ -1,0 +1,218 @@
+// extern "C" boundary of libpixpro_hip.so: argument validation, path selection, launches.
+// No torch types, no allocation, no synchronisation (include/pixpro_hip.h).
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "common.h"
+
+namespace pixpro {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return PIXPRO_ERR_LAUNCH;
+  }
+  return PIXPRO_OK;
+}
+
+// implemented in the kernel translation units
+bool fused_supported(const pixpro_problem& pb);
+int run_fused(const pixpro_problem& pb, const pixpro_dir* dirs, float* loss_n, float* pos_num, float* pos_mean,
+              hipStream_t st);
+size_t generic_workspace_bytes(const pixpro_problem& pb);
+int run_generic(const pixpro_problem& pb, const pixpro_dir* dirs, float* loss_n, float* pos_num, float* pos_mean,
+                float* loss, void* workspace, size_t ws_bytes, hipStream_t st, int mode);
+int run_finalize(const float* loss_n, float* loss, int B, int N, hipStream_t st);
+int run_featprop(const pixpro_problem& pb, const float* x, const float* v, const float* dY, float* Y, float* dx,
+                 float* dv, void* workspace, size_t ws_bytes, hipStream_t st);
+int run_upflow8(const float* in, float* out, int64_t planes, int h, int w, hipStream_t st);
+int run_concat_flow(const float* flows, float* out, int F1, int N, int Hf, int Wf, int is_norm, hipStream_t st);
+int run_fbc(const float* f, const float* b, uint8_t* mask, float* cycle, int N, int Hf, int Wf, float alpha1,
+            double alpha2, int is_norm, hipStream_t st);
+int run_flow_prepare(const float* lo_fwd, const float* lo_bwd, float* flow_fwd, float* flow_bwd, uint8_t* mask_fwd,
+                     uint8_t* mask_bwd, int32_t* invalid, int N, int F1, int h, int w, int flow_up, float alpha1,
+                     double alpha2, hipStream_t st);
+int run_mask_ratio(const uint8_t* mask, float* ratio, int N, int64_t pixels, hipStream_t st);
+int run_add_optical_flow(const pixpro_problem& pb, const float* flow, const float* xg, const float* yg,
+                         const uint8_t* mask, float* ox, float* oy, uint8_t* mg, hipStream_t st);
+int run_ema(const float* const* pq, float* const* pk, const int64_t* sizes, int count, double m, hipStream_t st);
+int run_lars(float* const* pp, const float* const* gp, float* const* bp, const int64_t* sizes, const float* wd,
+             const int32_t* adapt, int count, float lr, float momentum, float trust, float eps, int first_step,
+             float* norms2, hipStream_t st);
+int run_scale(float* buf, size_t n, const float* scale, hipStream_t st);
+
+namespace {
+
+int bad(const char* msg) {
+  set_error("%s", msg);
+  return PIXPRO_ERR_ARG;
+}
+
+int validate_problem(const pixpro_problem* pb, const pixpro_dir* dirs, bool need_v) {
+  if (!pb || !dirs) return bad("null problem / dirs");
+  if (pb->N < 1 || pb->C < 1 || pb->H < 1 || pb->W < 1) return bad("N, C, H, W must be positive");
+  if (pb->ndir < 1 || pb->ndir > PIXPRO_MAX_DIRS) return bad("ndir must be 1 or 2");
+  for (int d = 0; d < pb->ndir; ++d) {
+    const pixpro_dir& q = dirs[d];
+    if (!q.x || !q.k || !q.coord_q || !q.coord_k) return bad("x, k, coord_q, coord_k are required");
+    if (need_v && !q.v) return bad("v is required");
+    if (need_v && ((q.dx == nullptr) != (q.dv == nullptr))) return bad("dx and dv must be given together");
+    if ((q.dx == nullptr) != (dirs[0].dx == nullptr)) return bad("all directions must agree on wanting gradients");
+    if (q.flow && (pb->Hf < 1 || pb->Wf < 1)) return bad("flow given but Hf/Wf not set");
+    if (q.mask && !q.flow) return bad("mask given without flow");
+    if (q.flow && !q.size_dev && pb->Ho < 1) return bad("flow given without a frame size");
+  }
+  return PIXPRO_OK;
+}
+
+}  // namespace
+}  // namespace pixpro
+
+using namespace pixpro;
+
+extern "C" {
+
+int pixpro_version(void) { return 100; }
+
+const char* pixpro_last_error(void) { return g_err; }
+
+size_t pixpro_ppm_loss_workspace_bytes(const pixpro_problem* pb) {
+  if (!pb) return 0;
+  return generic_workspace_bytes(*pb);
+}
+
+int pixpro_ppm_loss_generic(const pixpro_problem* pb, const pixpro_dir* dirs, float* loss_n, float* pos_num,
+                            float* pos_mean, float* loss, void* workspace, size_t workspace_bytes, void* stream) {
+  if (int e = validate_problem(pb, dirs, true)) return e;
+  if (!loss_n || !pos_num || !pos_mean || !loss || !workspace) return bad("null output / workspace");
+  return run_generic(*pb, dirs, loss_n, pos_num, pos_mean, loss, workspace, workspace_bytes, (hipStream_t)stream, 0);
+}
+
+int pixpro_ppm_loss(const pixpro_problem* pb, const pixpro_dir* dirs, float* loss_n, float* pos_num, float* pos_mean,
+                    float* loss, void* workspace, size_t workspace_bytes, void* stream) {
+  if (int e = validate_problem(pb, dirs, true)) return e;
+  if (!loss_n || !pos_num || !pos_mean || !loss) return bad("null output");
+  bool aligned = true;
+  for (int d = 0; d < pb->ndir; ++d) {
+    const pixpro_dir& q = dirs[d];
+    const uintptr_t bits = (uintptr_t)q.x | (uintptr_t)q.v | (uintptr_t)q.k | (uintptr_t)q.dx | (uintptr_t)q.dv;
+    if (bits & 15) aligned = false;
+  }
+  if (fused_supported(*pb) && aligned) {
+    if (int e = run_fused(*pb, dirs, loss_n, pos_num, pos_mean, (hipStream_t)stream)) return e;
+    return run_finalize(loss_n, loss, pb->N * pb->ndir, pb->N, (hipStream_t)stream);
+  }
+  if (!workspace) return bad("this shape takes the staged path and needs a workspace");
+  return run_generic(*pb, dirs, loss_n, pos_num, pos_mean, loss, workspace, workspace_bytes, (hipStream_t)stream, 0);
+}
+
+int pixpro_scale_by_device_scalar(float* buf, size_t n, const float* scale_dev, void* stream) {
+  if (!buf || !scale_dev) return bad("null pointer");
+  return run_scale(buf, n, scale_dev, (hipStream_t)stream);
+}
+
+size_t pixpro_featprop_workspace_bytes(const pixpro_problem* pb) {
+  if (!pb) return 0;
+  pixpro_problem q = *pb;
+  q.ndir = 1;
+  return generic_workspace_bytes(q);
+}
+
+int pixpro_featprop_fwd(const pixpro_problem* pb, const float* x, const float* v, float* Y, void* workspace,
+                        size_t workspace_bytes, void* stream) {
+  if (!pb || !x || !v || !Y || !workspace) return bad("null pointer");
+  return run_featprop(*pb, x, v, nullptr, Y, nullptr, nullptr, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int pixpro_featprop_bwd(const pixpro_problem* pb, const float* x, const float* v, const float* dY, float* dx,
+                        float* dv, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!pb || !x || !v || !dY || !dx || !dv || !workspace) return bad("null pointer");
+  return run_featprop(*pb, x, v, dY, nullptr, dx, dv, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+size_t pixpro_regression_loss_workspace_bytes(const pixpro_problem* pb) {
+  return pixpro_featprop_workspace_bytes(pb);
+}
+
+int pixpro_regression_loss(const pixpro_problem* pb, const pixpro_dir* d, float* loss_n, float* pos_num,
+                           float* pos_mean, float* loss, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!pb || !d) return bad("null problem / dir");
+  pixpro_problem q = *pb;
+  q.ndir = 1;
+  if (int e = validate_problem(&q, d, false)) return e;
+  if (!loss_n || !pos_num || !pos_mean || !loss || !workspace) return bad("null output / workspace");
+  return run_generic(q, d, loss_n, pos_num, pos_mean, loss, workspace, workspace_bytes, (hipStream_t)stream, 1);
+}
+
+int pixpro_add_optical_flow(const pixpro_problem* pb, const float* flow, const float* x_grid, const float* y_grid,
+                            const uint8_t* mask, float* out_x, float* out_y, uint8_t* mask_grid, void* stream) {
+  if (!pb || !flow || !x_grid || !y_grid || !out_x || !out_y) return bad("null pointer");
+  if (pb->Hf < 1 || pb->Wf < 1 || pb->Ho < 2 || pb->Wo < 2) return bad("Hf, Wf, Ho, Wo must be set");
+  if ((mask == nullptr) != (mask_grid == nullptr)) return bad("mask and mask_grid go together");
+  return run_add_optical_flow(*pb, flow, x_grid, y_grid, mask, out_x, out_y, mask_grid, (hipStream_t)stream);
+}
+
+int pixpro_upflow8(const float* in, float* out, int64_t planes, int32_t h, int32_t w, void* stream) {
+  if (!in || !out) return bad("null pointer");
+  if (planes < 1 || h < 1 || w < 1) return bad("planes, h, w must be positive");
+  return run_upflow8(in, out, planes, h, w, (hipStream_t)stream);
+}
+
+int pixpro_concat_flow(const float* flows, float* out, int32_t F1, int32_t N, int32_t Hf, int32_t Wf,
+                       int32_t is_norm, void* stream) {
+  if (!flows || !out) return bad("null pointer");
+  if (F1 < 1 || N < 1 || Hf < 2 || Wf < 2) return bad("F1, N >= 1 and Hf, Wf >= 2 required");
+  return run_concat_flow(flows, out, F1, N, Hf, Wf, is_norm, (hipStream_t)stream);
+}
+
+int pixpro_fbc_mask(const float* flow_fwd, const float* flow_bwd, uint8_t* mask, float* cycle, int32_t N, int32_t Hf,
+                    int32_t Wf, float alpha1, double alpha2, int32_t is_norm, void* stream) {
+  if (!flow_fwd || !flow_bwd || !mask) return bad("null pointer");
+  if (N < 1 || Hf < 2 || Wf < 2) return bad("N >= 1 and Hf, Wf >= 2 required");
+  return run_fbc(flow_fwd, flow_bwd, mask, cycle, N, Hf, Wf, alpha1, alpha2, is_norm, (hipStream_t)stream);
+}
+
+int pixpro_flow_prepare(const float* lo_fwd, const float* lo_bwd, float* flow_fwd, float* flow_bwd, uint8_t* mask_fwd,
+                        uint8_t* mask_bwd, int32_t* invalid_count, int32_t N, int32_t F1, int32_t h, int32_t w,
+                        int32_t flow_up, float alpha1, double alpha2, void* stream) {
+  if (!lo_fwd || !lo_bwd || !flow_fwd || !flow_bwd) return bad("null pointer");
+  if ((mask_fwd == nullptr) != (mask_bwd == nullptr)) return bad("mask_fwd and mask_bwd go together");
+  if (N < 1 || F1 < 1 || h < 2 || w < 2) return bad("N, F1 >= 1 and h, w >= 2 required");
+  return run_flow_prepare(lo_fwd, lo_bwd, flow_fwd, flow_bwd, mask_fwd, mask_bwd, invalid_count, N, F1, h, w,
+                          flow_up, alpha1, alpha2, (hipStream_t)stream);
+}
+
+int pixpro_mask_ratio(const uint8_t* mask, float* ratio, int32_t N, int64_t pixels, void* stream) {
+  if (!mask || !ratio) return bad("null pointer");
+  if (N < 1 || pixels < 1) return bad("N, pixels must be positive");
+  return run_mask_ratio(mask, ratio, N, pixels, (hipStream_t)stream);
+}
+
+int pixpro_ema_update(const float* const* pq_ptrs, float* const* pk_ptrs, const int64_t* sizes, int32_t count,
+                      double m, void* stream) {
+  if (!pq_ptrs || !pk_ptrs || !sizes) return bad("null pointer");
+  if (count < 1 || count > 65535) return bad("count out of range");
+  return run_ema(pq_ptrs, pk_ptrs, sizes, count, m, (hipStream_t)stream);
+}
+
+int pixpro_lars_sgd_step(float* const* p_ptrs, const float* const* g_ptrs, float* const* buf_ptrs,
+                         const int64_t* sizes, const float* wd, const int32_t* adapt, int32_t count, float lr,
+                         float momentum, float trust_coef, float eps, int32_t first_step, float* norms2,
+                         void* stream) {
+  if (!p_ptrs || !g_ptrs || !buf_ptrs || !sizes || !wd || !adapt || !norms2) return bad("null pointer");
+  if (count < 1 || count > 65535) return bad("count out of range");
+  return run_lars(p_ptrs, g_ptrs, buf_ptrs, sizes, wd, adapt, count, lr, momentum, trust_coef, eps, first_step,
+                  norms2, (hipStream_t)stream);
+}
+
+}  // extern "C"

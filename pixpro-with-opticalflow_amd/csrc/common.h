@@ -1,0 +1,233 @@
+// Shared device helpers for libpixpro_hip (gfx950 only).  Compiled with -ffp-contract=off:
+// every fused multiply-add below is written explicitly (__builtin_fmaf) where the reference
+// arithmetic (ATen CPU kernels on an FMA-capable x86 build) fuses, and nowhere else, so the
+// coordinate / flow pipeline can be reproduced bit for bit (see oracle/pixpro_oracle.py).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/pixpro_hip.h"
+
+#define WAVE 64
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace pixpro {
+
+struct Dirs {
+  pixpro_dir d[PIXPRO_MAX_DIRS];
+};
+
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+// ---------------------------------------------------------------------------------------
+// v_mfma_f32_16x16x4_f32: D[16x16] += A[16x4] * B[4x16], exact fp32 (k-ordered fma chain).
+// lane l supplies a = A[l&15][l>>4], b = B[l>>4][l&15]; reg r of the result is
+// D[(l>>4)*4 + r][l&15].  PIXPRO_EMULATE_MFMA swaps in a shuffle-based VALU version with the
+// identical contract (used only to bisect layout bugs on hardware).
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+#ifdef PIXPRO_EMULATE_MFMA
+  const int l = threadIdx.x & 63;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float bk = __shfl(b, k * 16 + (l & 15), 64);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float ak = __shfl(a, k * 16 + (l >> 4) * 4 + r, 64);
+      c[r] = __builtin_fmaf(ak, bk, c[r]);
+    }
+  }
+  return c;
+#else
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+#endif
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------
+// Crop geometry, contrast/models/PixPro.py:140-157,168-175.  c = coord row [10].
+// ---------------------------------------------------------------------------------------
+struct Crop {
+  float bw, bh, x0, y0;
+};
+
+__device__ __forceinline__ Crop crop_of(const float* c, int H, int W) {
+  Crop g;
+  g.bw = (c[2] - c[0]) / (float)W;
+  g.bh = (c[3] - c[1]) / (float)H;
+  g.x0 = c[0];
+  g.y0 = c[1];
+  return g;
+}
+
+__device__ __forceinline__ float bin_diag(const Crop& g, float wo1, float ho1) {
+  float a = g.bw * wo1, b = g.bh * ho1;
+  return sqrtf(a * a + b * b);
+}
+
+// centre of bin (row i, col j) in original-frame pixels
+__device__ __forceinline__ float centre_x(const Crop& g, int j, float wo1) {
+  return (((float)j + 0.5f) * g.bw + g.x0) * wo1;
+}
+__device__ __forceinline__ float centre_y(const Crop& g, int i, float ho1) {
+  return (((float)i + 0.5f) * g.bh + g.y0) * ho1;
+}
+
+// ---------------------------------------------------------------------------------------
+// grid_sample(bilinear, zeros, align_corners=True) on one 2-channel image (ATen CPU order,
+// oracle.bilinear_sample).  gx, gy normalised.  `pre` is applied to every tap of channel
+// 0/1 before interpolation (used to sample normalize_flow(f) without materialising it).
+// ---------------------------------------------------------------------------------------
+struct TapNone {
+  __device__ __forceinline__ float x(float v) const { return v; }
+  __device__ __forceinline__ float y(float v) const { return v; }
+};
+struct TapNormFlow {  // util.py:342-348: 2*f/(wd-1), 2*f/(ht-1)
+  float wd1, ht1;
+  __device__ __forceinline__ float x(float v) const { return 2.f * v / wd1; }
+  __device__ __forceinline__ float y(float v) const { return 2.f * v / ht1; }
+};
+
+// Tap sources: a dense 2-channel map, or the x8 bilinear up-sampling (upflow8,
+// contrast/flow/utils/utils.py:87-89) of a low-resolution map evaluated on the fly with
+// exactly the arithmetic of the materialised version (oracle.upflow8).
+struct FetchDense {
+  const float* __restrict__ cx;
+  const float* __restrict__ cy;
+  int Wf;
+  __device__ __forceinline__ void operator()(int y, int x, float& vx, float& vy) const {
+    const int o = y * Wf + x;
+    vx = cx[o]; vy = cy[o];
+  }
+};
+
+struct Up8Axis {
+  int i0, i1;
+  float l0, l1;
+};
+__device__ __forceinline__ Up8Axis up8_axis(int dst, int n_in, float scale) {
+  Up8Axis a;
+  const float src = (float)dst * scale;
+  a.i0 = min((int)src, n_in - 1);
+  a.i1 = min(a.i0 + 1, n_in - 1);
+  a.l1 = fminf(fmaxf(src - (float)a.i0, 0.f), 1.f);
+  a.l0 = 1.f - a.l1;
+  return a;
+}
+__device__ __forceinline__ float up8_scale(int n_in) {
+  return n_in > 1 ? (float)(n_in - 1) / (float)(8 * n_in - 1) : 0.f;
+}
+__device__ __forceinline__ float up8_combine(float a, float b, float c, float d, const Up8Axis& ay,
+                                             const Up8Axis& ax) {
+  float acc = b * (ay.l0 * ax.l1);
+  acc = __builtin_fmaf(a, ay.l0 * ax.l0, acc);
+  acc = __builtin_fmaf(c, ay.l1 * ax.l0, acc);
+  acc = __builtin_fmaf(d, ay.l1 * ax.l1, acc);
+  return 8.f * acc;
+}
+struct FetchUp8 {
+  const float* __restrict__ lx;   // low-res channel 0 [h][w]
+  const float* __restrict__ ly;   // low-res channel 1
+  int h, w;
+  float sy, sx;
+  __device__ __forceinline__ void operator()(int y, int x, float& vx, float& vy) const {
+    const Up8Axis ay = up8_axis(y, h, sy), ax = up8_axis(x, w, sx);
+    const int o00 = ay.i0 * w + ax.i0, o01 = ay.i0 * w + ax.i1, o10 = ay.i1 * w + ax.i0, o11 = ay.i1 * w + ax.i1;
+    vx = up8_combine(lx[o00], lx[o01], lx[o10], lx[o11], ay, ax);
+    vy = up8_combine(ly[o00], ly[o01], ly[o10], ly[o11], ay, ax);
+  }
+};
+
+template <class Fetch, class Tap>
+__device__ __forceinline__ void bilinear2(const Fetch& fetch, int Hf, int Wf, float gx, float gy, const Tap& tap,
+                                          float& ox, float& oy) {
+  const float ix = (gx + 1.f) * ((float)(Wf - 1) / 2.f);
+  const float iy = (gy + 1.f) * ((float)(Hf - 1) / 2.f);
+  const float xw = floorf(ix), yn = floorf(iy);
+  const float w = ix - xw, e = 1.f - w, n = iy - yn, s = 1.f - n;
+  const float nw = s * e, ne = s * w, sw = n * e, se = n * w;
+  // float -> int keeping far-away (or NaN) coordinates out of range
+  const int x0 = (xw > -2.f && xw < (float)(Wf + 1)) ? (int)xw : -2;
+  const int y0 = (yn > -2.f && yn < (float)(Hf + 1)) ? (int)yn : -2;
+  const int x1 = x0 + 1, y1 = y0 + 1;
+  const bool bx0 = x0 >= 0 && x0 < Wf, bx1 = x1 >= 0 && x1 < Wf;
+  const bool by0 = y0 >= 0 && y0 < Hf, by1 = y1 >= 0 && y1 < Hf;
+  float ax = 0.f, ay = 0.f, bxv = 0.f, byv = 0.f, cxv = 0.f, cyv = 0.f, dxv = 0.f, dyv = 0.f;
+  if (by0 && bx0) { fetch(y0, x0, ax, ay); ax = tap.x(ax); ay = tap.y(ay); }
+  if (by0 && bx1) { fetch(y0, x1, bxv, byv); bxv = tap.x(bxv); byv = tap.y(byv); }
+  if (by1 && bx0) { fetch(y1, x0, cxv, cyv); cxv = tap.x(cxv); cyv = tap.y(cyv); }
+  if (by1 && bx1) { fetch(y1, x1, dxv, dyv); dxv = tap.x(dxv); dyv = tap.y(dyv); }
+  ox = __builtin_fmaf(dxv, se, __builtin_fmaf(cxv, sw, __builtin_fmaf(bxv, ne, ax * nw)));
+  oy = __builtin_fmaf(dyv, se, __builtin_fmaf(cyv, sw, __builtin_fmaf(byv, ne, ay * nw)));
+}
+
+// grid_sample(nearest, zeros, align_corners=True) of a uint8 mask -> bool (PixPro.py:68-70)
+__device__ __forceinline__ bool nearest_mask(const uint8_t* __restrict__ m, int Hf, int Wf, float gx,
+                                             float gy) {
+  const float ix = (gx + 1.f) * ((float)(Wf - 1) / 2.f);
+  const float iy = (gy + 1.f) * ((float)(Hf - 1) / 2.f);
+  const float xr = rintf(ix), yr = rintf(iy);
+  if (!(xr >= 0.f && xr < (float)Wf && yr >= 0.f && yr < (float)Hf)) return false;
+  return m[(int)yr * Wf + (int)xr] != 0;
+}
+
+// add_optical_flow for one point (PixPro.py:46-89).  (x, y) original-frame pixels.
+struct FlowGeom {
+  int Hf, Wf;
+  float wo1, ho1;     // Wo-1, Ho-1
+  float rw, rh;       // Wf/Wo, Hf/Ho evaluated in double then rounded (python floats)
+  bool diff;
+};
+
+__device__ __forceinline__ FlowGeom flow_geom(int Hf, int Wf, int Ho, int Wo) {
+  FlowGeom g;
+  g.Hf = Hf; g.Wf = Wf;
+  g.wo1 = (float)(Wo - 1); g.ho1 = (float)(Ho - 1);
+  g.rw = (float)((double)Wf / (double)Wo);
+  g.rh = (float)((double)Hf / (double)Ho);
+  g.diff = (Hf != Ho) || (Wf != Wo);
+  return g;
+}
+
+__device__ __forceinline__ void displace_point(const float* __restrict__ flow_n, const uint8_t* __restrict__ mask_n,
+                                               const FlowGeom& g, float x, float y, float& ox, float& oy,
+                                               bool& valid) {
+  const float gx = 2.f * (x / g.wo1) - 1.f;
+  const float gy = 2.f * (y / g.ho1) - 1.f;
+  float fx, fy;
+  bilinear2(FetchDense{flow_n, flow_n + (size_t)g.Hf * g.Wf, g.Wf}, g.Hf, g.Wf, gx, gy, TapNone(), fx, fy);
+  valid = mask_n ? nearest_mask(mask_n, g.Hf, g.Wf, gx, gy) : true;
+  if (g.diff) {
+    ox = (x * g.rw + fx) / g.rw;
+    oy = (y * g.rh + fy) / g.rh;
+  } else {
+    ox = x + fx;
+    oy = y + fy;
+  }
+}
+
+// Frame size for one problem: explicit device tensor, explicit ints, or coord_q[0][9], [0][8].
+__device__ __forceinline__ void frame_size(const pixpro_problem& pb, const pixpro_dir& d, int& Ho, int& Wo) {
+  if (d.size_dev) { Ho = d.size_dev[0]; Wo = d.size_dev[1]; }
+  else if (pb.Ho > 0) { Ho = pb.Ho; Wo = pb.Wo; }
+  else { Ho = (int)d.coord_q[9]; Wo = (int)d.coord_q[8]; }
+}
+
+// A = clamp(S,min=c) (+1e-6 if p<1) ** p  and  D = dA/dS  (PixPro.py:355-358).
+__device__ __forceinline__ void pow_map(float S, float p, float clampv, float& A, float& D) {
+  float B = fmaxf(S, clampv);
+  if (p < 1.f) B = B + 1e-6f;
+  const float pass = (S >= clampv) ? 1.f : 0.f;
+  if (p == 2.f) { A = B * B; D = 2.f * B * pass; }
+  else if (p == 1.f) { A = B; D = pass; }
+  else { A = powf(B, p); D = p * powf(B, p - 1.f) * pass; }
+}
+
+}  // namespace pixpro

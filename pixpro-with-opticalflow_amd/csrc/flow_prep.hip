@@ -1,0 +1,337 @@
+// Flow preparation kernels (HBM-bound, one thread per full-resolution pixel, coalesced along x).
+//
+// Reference: contrast/util.py:174-248 (apply_optical_flow, file mode), :300-330 (concat_flow),
+// :252-297 (forward_backward_consistency), :333-366 (normalise helpers, calc_mask_ratio),
+// contrast/flow/utils/utils.py:87-89 (upflow8), contrast/models/PixPro.py:46-89
+// (add_optical_flow).  Arithmetic order follows oracle/pixpro_oracle.py (bit-exact targets).
+#include "common.h"
+
+namespace pixpro {
+namespace {
+
+constexpr int TPB = 256;
+inline unsigned blocks_for(size_t n) { return (unsigned)((n + TPB - 1) / TPB); }
+
+// ---- K5: upflow8 ----------------------------------------------------------------------
+__global__ void k_upflow8(const float* __restrict__ in, float* __restrict__ out, int64_t planes, int h, int w) {
+  const int Wf = 8 * w, Hf = 8 * h;
+  const size_t idx = (size_t)blockIdx.x * TPB + threadIdx.x;
+  if (idx >= (size_t)planes * Hf * Wf) return;
+  const int x = (int)(idx % Wf), y = (int)((idx / Wf) % Hf);
+  const size_t pl = idx / ((size_t)Wf * Hf);
+  const float* p = in + pl * h * w;
+  const Up8Axis ay = up8_axis(y, h, up8_scale(h)), ax = up8_axis(x, w, up8_scale(w));
+  out[idx] = up8_combine(p[ay.i0 * w + ax.i0], p[ay.i0 * w + ax.i1], p[ay.i1 * w + ax.i0], p[ay.i1 * w + ax.i1],
+                         ay, ax);
+}
+
+// ---- K6: concat_flow ------------------------------------------------------------------
+// One chain per pixel.  `Source` yields the t-th flow of sample n as a fetch functor.
+struct DenseSource {   // flows [F1,N,2,Hf,Wf]
+  const float* flows;
+  int N, Hf, Wf;
+  __device__ __forceinline__ FetchDense at(int t, int n) const {
+    const float* p = flows + ((size_t)t * N + n) * 2 * Hf * Wf;
+    return FetchDense{p, p + (size_t)Hf * Wf, Wf};
+  }
+};
+struct Up8Source {     // lo [N,F1,2,h,w] (loader layout), up-sampled lazily
+  const float* lo;
+  int F1, h, w;
+  __device__ __forceinline__ FetchUp8 at(int t, int n) const {
+    const float* p = lo + ((size_t)n * F1 + t) * 2 * h * w;
+    return FetchUp8{p, p + (size_t)h * w, h, w, up8_scale(h), up8_scale(w)};
+  }
+};
+struct LoSource {      // lo [N,F1,2,h,w] used at its own resolution (flow_up == False)
+  const float* lo;
+  int F1, h, w;
+  __device__ __forceinline__ FetchDense at(int t, int n) const {
+    const float* p = lo + ((size_t)n * F1 + t) * 2 * h * w;
+    return FetchDense{p, p + (size_t)h * w, w};
+  }
+};
+
+template <class Source>
+__device__ __forceinline__ void chain_pixel(const Source& src, int F1, int n, int Hf, int Wf, int y, int x,
+                                            int is_norm, float& ox, float& oy) {
+  const float wd1 = (float)(Wf - 1), ht1 = (float)(Hf - 1);
+  if (F1 == 1) {                                   // util.py:303-308: a copy of the only flow
+    src.at(0, n)(y, x, ox, oy);
+    if (is_norm) { ox = 2.f * ox / wd1; oy = 2.f * oy / ht1; }
+    return;
+  }
+  const float x0 = (float)x, y0 = (float)y;
+  const float x0n = 2.f * x0 / wd1 - 1.f, y0n = 2.f * y0 / ht1 - 1.f;   // normalize_coord, util.py:333-339
+  if (is_norm) {                                   // util.py:316-319
+    float cx = x0n, cy = y0n;
+    for (int t = 0; t < F1; ++t) {
+      float fx, fy;
+      bilinear2(src.at(t, n), Hf, Wf, cx, cy, TapNormFlow{wd1, ht1}, fx, fy);
+      cx = cx + fx; cy = cy + fy;
+    }
+    ox = cx - x0n; oy = cy - y0n;
+  } else {                                         // util.py:320-323
+    float cx = x0, cy = y0;
+    for (int t = 0; t < F1; ++t) {
+      float fx, fy;
+      bilinear2(src.at(t, n), Hf, Wf, 2.f * cx / wd1 - 1.f, 2.f * cy / ht1 - 1.f, TapNone(), fx, fy);
+      cx = cx + fx; cy = cy + fy;
+    }
+    ox = cx - x0; oy = cy - y0;
+  }
+}
+
+template <class Source>
+__global__ void k_chain(Source s0, Source s1, float* __restrict__ out0, float* __restrict__ out1, int F1, int N,
+                        int Hf, int Wf, int is_norm) {
+  const size_t HW = (size_t)Hf * Wf;
+  const size_t idx = (size_t)blockIdx.x * TPB + threadIdx.x;
+  if (idx >= (size_t)N * HW) return;
+  const int n = (int)(idx / HW);
+  const size_t r = idx % HW;
+  const int y = (int)(r / Wf), x = (int)(r % Wf);
+  const Source& src = blockIdx.y ? s1 : s0;
+  float* out = blockIdx.y ? out1 : out0;
+  float ox, oy;
+  chain_pixel(src, F1, n, Hf, Wf, y, x, is_norm, ox, oy);
+  out[(size_t)n * 2 * HW + r] = ox;
+  out[(size_t)n * 2 * HW + HW + r] = oy;
+}
+
+// ---- K7: forward_backward_consistency ----------------------------------------------------
+// (fx, fy): forward flow at the pixel; `bwd` fetches the backward flow (pixel units unless
+// is_norm).  Returns validity; cycle flow in (cx, cy).
+template <class Fetch>
+__device__ __forceinline__ bool fbc_pixel(float fx, float fy, const Fetch& bwd, int Hf, int Wf, int y, int x,
+                                          float alpha1, float a2, int is_norm, float& cx, float& cy) {
+  const float wd1 = (float)(Wf - 1), ht1 = (float)(Hf - 1);
+  float fnx = fx, fny = fy;
+  if (!is_norm) { fnx = 2.f * fx / wd1; fny = 2.f * fy / ht1; }            // normalize_flow
+  const float c1x = (2.f * (float)x / wd1 - 1.f) + fnx;                     // util.py:276
+  const float c1y = (2.f * (float)y / ht1 - 1.f) + fny;
+  const bool inside = (fabsf(c1x) < 1.f) && (fabsf(c1y) < 1.f);             // :277
+  float bx, by;
+  if (is_norm) bilinear2(bwd, Hf, Wf, c1x, c1y, TapNone(), bx, by);
+  else bilinear2(bwd, Hf, Wf, c1x, c1y, TapNormFlow{wd1, ht1}, bx, by);     // :279
+  cx = fnx + bx; cy = fny + by;                                             // :280
+  const float cyc = cx * cx + cy * cy;                                      // :294
+  const float eps = alpha1 * ((fnx * fnx + fny * fny) + (bx * bx + by * by)) + a2;   // :295
+  return inside && ((cyc - eps) <= 0.f);                                    // :297
+}
+
+// alpha_2 / sqrt(h^2+w^2): torch.sqrt of an int64 tensor -> fp32, .item() -> double (util.py:290-292)
+inline float fbc_a2(double alpha2, int Hf, int Wf) {
+  const float diag = sqrtf((float)((int64_t)Hf * Hf + (int64_t)Wf * Wf));
+  return (float)(alpha2 / (double)diag);
+}
+
+__global__ void k_fbc(const float* __restrict__ f, const float* __restrict__ bw, uint8_t* __restrict__ mask,
+                      float* __restrict__ cycle, int32_t* __restrict__ invalid, int N, int Hf, int Wf, float alpha1,
+                      float a2, int is_norm) {
+  const size_t HW = (size_t)Hf * Wf;
+  const size_t idx = (size_t)blockIdx.x * TPB + threadIdx.x;
+  bool bad = false;
+  int n = 0;
+  if (idx < (size_t)N * HW) {
+    n = (int)(idx / HW);
+    const size_t r = idx % HW;
+    const int y = (int)(r / Wf), x = (int)(r % Wf);
+    const float* fp = f + (size_t)n * 2 * HW;
+    const float* bp = bw + (size_t)n * 2 * HW;
+    float cx, cy;
+    const bool ok = fbc_pixel(fp[r], fp[HW + r], FetchDense{bp, bp + HW, Wf}, Hf, Wf, y, x, alpha1, a2, is_norm,
+                              cx, cy);
+    mask[idx] = ok ? 1 : 0;
+    if (cycle) { cycle[(size_t)n * 2 * HW + r] = cx; cycle[(size_t)n * 2 * HW + HW + r] = cy; }
+    bad = !ok;
+  }
+  if (invalid) {
+    // a block never straddles more than two samples when HW >= TPB; count per wave and add once
+    const unsigned long long bits = __ballot(bad);
+    const int n0 = __shfl(n, 0, 64);
+    const bool uniform = __all(n == n0 || idx >= (size_t)N * HW);
+    if (uniform) {
+      if ((threadIdx.x & 63) == 0 && bits) atomicAdd(&invalid[n0], __popcll(bits));
+    } else if (bad) {
+      atomicAdd(&invalid[n], 1);
+    }
+  }
+}
+
+// ---- fused file-mode apply_optical_flow for F-1 == 1 (nframe = 2) -------------------------
+// Per pixel, both directions: composed flow = up8(lo) (a copy, util.py:303-308) and the two
+// consistency masks, with the opposite direction's taps recomputed from the low-res map.
+// HBM traffic: read the low-res maps, write 2 flows + 2 masks; nothing else.
+template <class Source>
+__global__ void k_prepare_single(Source sf, Source sb, float* __restrict__ flow_fwd, float* __restrict__ flow_bwd,
+                                 uint8_t* __restrict__ mask_fwd, uint8_t* __restrict__ mask_bwd,
+                                 int32_t* __restrict__ invalid, int N, int Hf, int Wf, float alpha1, float a2) {
+  const size_t HW = (size_t)Hf * Wf;
+  const size_t idx = (size_t)blockIdx.x * TPB + threadIdx.x;
+  bool badf = false, badb = false;
+  int n = 0;
+  if (idx < (size_t)N * HW) {
+    n = (int)(idx / HW);
+    const size_t r = idx % HW;
+    const int y = (int)(r / Wf), x = (int)(r % Wf);
+    const auto ff = sf.at(0, n);
+    const auto fb = sb.at(0, n);
+    float fx, fy, bx, by;
+    ff(y, x, fx, fy);
+    fb(y, x, bx, by);
+    flow_fwd[(size_t)n * 2 * HW + r] = fx; flow_fwd[(size_t)n * 2 * HW + HW + r] = fy;
+    flow_bwd[(size_t)n * 2 * HW + r] = bx; flow_bwd[(size_t)n * 2 * HW + HW + r] = by;
+    if (mask_fwd) {
+      float cx, cy;
+      const bool okf = fbc_pixel(fx, fy, fb, Hf, Wf, y, x, alpha1, a2, 0, cx, cy);
+      const bool okb = fbc_pixel(bx, by, ff, Hf, Wf, y, x, alpha1, a2, 0, cx, cy);
+      mask_fwd[idx] = okf ? 1 : 0;
+      mask_bwd[idx] = okb ? 1 : 0;
+      badf = !okf; badb = !okb;
+    }
+  }
+  if (invalid && mask_fwd) {
+    const unsigned long long bf = __ballot(badf), bb = __ballot(badb);
+    const int n0 = __shfl(n, 0, 64);
+    const bool uniform = __all(n == n0 || idx >= (size_t)N * HW);
+    if (uniform) {
+      if ((threadIdx.x & 63) == 0) {
+        if (bf) atomicAdd(&invalid[n0], __popcll(bf));
+        if (bb) atomicAdd(&invalid[N + n0], __popcll(bb));
+      }
+    } else {
+      if (badf) atomicAdd(&invalid[n], 1);
+      if (badb) atomicAdd(&invalid[N + n], 1);
+    }
+  }
+}
+
+// ---- K8: calc_mask_ratio -----------------------------------------------------------------
+__global__ void k_mask_ratio(const uint8_t* __restrict__ mask, float* __restrict__ ratio, int64_t pixels) {
+  __shared__ int red[TPB / WAVE];
+  const int n = blockIdx.x;
+  const uint8_t* m = mask + (size_t)n * pixels;
+  int acc = 0;
+  for (int64_t e = threadIdx.x; e < pixels; e += TPB) acc += (m[e] == 0);
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int t = 0;
+    for (int w = 0; w < TPB / WAVE; ++w) t += red[w];
+    ratio[n] = (float)((double)t / (double)pixels);
+  }
+}
+
+// ---- K4 stand-alone: add_optical_flow ------------------------------------------------------
+__global__ void k_add_optical_flow(pixpro_problem pb, const float* __restrict__ flow, const float* __restrict__ xg,
+                                   const float* __restrict__ yg, const uint8_t* __restrict__ mask,
+                                   float* __restrict__ ox, float* __restrict__ oy, uint8_t* __restrict__ mg) {
+  const int P = pb.H * pb.W;
+  const size_t idx = (size_t)blockIdx.x * TPB + threadIdx.x;
+  if (idx >= (size_t)pb.N * P) return;
+  const int n = (int)(idx / P);
+  const FlowGeom fg = flow_geom(pb.Hf, pb.Wf, pb.Ho, pb.Wo);
+  float x, y;
+  bool valid;
+  displace_point(flow + (size_t)n * 2 * pb.Hf * pb.Wf, mask ? mask + (size_t)n * pb.Hf * pb.Wf : nullptr, fg,
+                 xg[idx], yg[idx], x, y, valid);
+  ox[idx] = x; oy[idx] = y;
+  if (mg) mg[idx] = valid ? 1 : 0;
+}
+
+#define CHECKED(what)                      \
+  do {                                     \
+    if (int e = check_launch(what)) return e; \
+  } while (0)
+
+}  // namespace
+
+int run_upflow8(const float* in, float* out, int64_t planes, int h, int w, hipStream_t st) {
+  const size_t n = (size_t)planes * 64 * h * w;
+  hipLaunchKernelGGL(k_upflow8, dim3(blocks_for(n)), dim3(TPB), 0, st, in, out, planes, h, w);
+  CHECKED("k_upflow8");
+  return PIXPRO_OK;
+}
+
+int run_concat_flow(const float* flows, float* out, int F1, int N, int Hf, int Wf, int is_norm, hipStream_t st) {
+  DenseSource s{flows, N, Hf, Wf};
+  const size_t n = (size_t)N * Hf * Wf;
+  hipLaunchKernelGGL(k_chain<DenseSource>, dim3(blocks_for(n), 1), dim3(TPB), 0, st, s, s, out, out, F1, N, Hf, Wf,
+                     is_norm);
+  CHECKED("k_chain");
+  return PIXPRO_OK;
+}
+
+int run_fbc(const float* f, const float* b, uint8_t* mask, float* cycle, int N, int Hf, int Wf, float alpha1,
+            double alpha2, int is_norm, hipStream_t st) {
+  const size_t n = (size_t)N * Hf * Wf;
+  hipLaunchKernelGGL(k_fbc, dim3(blocks_for(n)), dim3(TPB), 0, st, f, b, mask, cycle, (int32_t*)nullptr, N, Hf, Wf,
+                     alpha1, fbc_a2(alpha2, Hf, Wf), is_norm);
+  CHECKED("k_fbc");
+  return PIXPRO_OK;
+}
+
+int run_flow_prepare(const float* lo_fwd, const float* lo_bwd, float* flow_fwd, float* flow_bwd, uint8_t* mask_fwd,
+                     uint8_t* mask_bwd, int32_t* invalid, int N, int F1, int h, int w, int flow_up, float alpha1,
+                     double alpha2, hipStream_t st) {
+  const int Hf = flow_up ? 8 * h : h, Wf = flow_up ? 8 * w : w;
+  const size_t n = (size_t)N * Hf * Wf;
+  const float a2 = fbc_a2(alpha2, Hf, Wf);
+  if (invalid) {
+    if (hipMemsetAsync(invalid, 0, sizeof(int32_t) * 2 * N, st) != hipSuccess) {
+      set_error("hipMemsetAsync failed");
+      return PIXPRO_ERR_LAUNCH;
+    }
+  }
+  if (F1 == 1) {
+    if (flow_up) {
+      Up8Source sf{lo_fwd, F1, h, w}, sb{lo_bwd, F1, h, w};
+      hipLaunchKernelGGL(k_prepare_single<Up8Source>, dim3(blocks_for(n)), dim3(TPB), 0, st, sf, sb, flow_fwd,
+                         flow_bwd, mask_fwd, mask_bwd, invalid, N, Hf, Wf, alpha1, a2);
+    } else {
+      LoSource sf{lo_fwd, F1, h, w}, sb{lo_bwd, F1, h, w};
+      hipLaunchKernelGGL(k_prepare_single<LoSource>, dim3(blocks_for(n)), dim3(TPB), 0, st, sf, sb, flow_fwd,
+                         flow_bwd, mask_fwd, mask_bwd, invalid, N, Hf, Wf, alpha1, a2);
+    }
+    CHECKED("k_prepare_single");
+    return PIXPRO_OK;
+  }
+  // F-1 > 1: chains (up-sampling evaluated lazily, both directions in one launch), then masks
+  if (flow_up) {
+    Up8Source sf{lo_fwd, F1, h, w}, sb{lo_bwd, F1, h, w};
+    hipLaunchKernelGGL(k_chain<Up8Source>, dim3(blocks_for(n), 2), dim3(TPB), 0, st, sf, sb, flow_fwd, flow_bwd, F1,
+                       N, Hf, Wf, 0);
+  } else {
+    LoSource sf{lo_fwd, F1, h, w}, sb{lo_bwd, F1, h, w};
+    hipLaunchKernelGGL(k_chain<LoSource>, dim3(blocks_for(n), 2), dim3(TPB), 0, st, sf, sb, flow_fwd, flow_bwd, F1,
+                       N, Hf, Wf, 0);
+  }
+  CHECKED("k_chain");
+  if (mask_fwd) {
+    hipLaunchKernelGGL(k_fbc, dim3(blocks_for(n)), dim3(TPB), 0, st, flow_fwd, flow_bwd, mask_fwd, (float*)nullptr,
+                       invalid, N, Hf, Wf, alpha1, a2, 0);
+    CHECKED("k_fbc");
+    hipLaunchKernelGGL(k_fbc, dim3(blocks_for(n)), dim3(TPB), 0, st, flow_bwd, flow_fwd, mask_bwd, (float*)nullptr,
+                       invalid ? invalid + N : nullptr, N, Hf, Wf, alpha1, a2, 0);
+    CHECKED("k_fbc");
+  }
+  return PIXPRO_OK;
+}
+
+int run_mask_ratio(const uint8_t* mask, float* ratio, int N, int64_t pixels, hipStream_t st) {
+  hipLaunchKernelGGL(k_mask_ratio, dim3(N), dim3(TPB), 0, st, mask, ratio, pixels);
+  CHECKED("k_mask_ratio");
+  return PIXPRO_OK;
+}
+
+int run_add_optical_flow(const pixpro_problem& pb, const float* flow, const float* xg, const float* yg,
+                         const uint8_t* mask, float* ox, float* oy, uint8_t* mg, hipStream_t st) {
+  const size_t n = (size_t)pb.N * pb.H * pb.W;
+  hipLaunchKernelGGL(k_add_optical_flow, dim3(blocks_for(n)), dim3(TPB), 0, st, pb, flow, xg, yg, mask, ox, oy, mg);
+  CHECKED("k_add_optical_flow");
+  return PIXPRO_OK;
+}
+
+}  // namespace pixpro

@@ -1,0 +1,118 @@
+"""HIP flow preparation vs the reference's golden vectors (bit-exact targets) and the oracle."""
+import types
+
+import pytest
+import torch
+
+from conftest import load_golden
+from gpu_utils import to_dev
+
+pytestmark = pytest.mark.gpu
+
+
+def test_upflow8_bitwise(dev):
+    from contrast import util
+    g = load_golden("upflow8")
+    out = util.upflow8(g["flow"].to(dev)).cpu()
+    assert torch.equal(out, g["out"])
+
+
+@pytest.mark.parametrize("n", [1, 2, 5])
+def test_concat_flow_bitwise(dev, n):
+    from contrast import util
+    g = load_golden(f"concat_flow_{n}")
+    assert torch.equal(util.concat_flow(g["flows"].to(dev)).cpu(), g["out"])
+    assert torch.equal(util.concat_flow(g["flows"].to(dev), is_norm=True).cpu(), g["out_norm"])
+
+
+def test_fbc_exact(dev):
+    from contrast import util
+    g = load_golden("fbc")
+    _, _, (m, cyc) = util.forward_backward_consistency(g["flow_fwd"].to(dev), g["flow_bwd"].to(dev),
+                                                       alpha_1=g["alpha1"], alpha_2=g["alpha2"])
+    assert torch.equal(m.cpu(), g["mask"])
+    assert torch.equal(cyc.cpu(), g["cycle"])
+    r = util.calc_mask_ratio(m).cpu()
+    assert torch.allclose(r, g["ratio"], atol=1e-6, rtol=0)
+
+
+def _args(up, **kw):
+    base = dict(alpha1=0.01, alpha2=0.5, use_flow_frames=False, use_flow_file=True, flow_up=up,
+                flow_cat_norm=False, debug=False)
+    base.update(kw)
+    return types.SimpleNamespace(**base)
+
+
+def _data(fw, bw, size, nfr, dev):
+    N = fw.shape[0]
+    return [None, None, None, None, None, [torch.zeros(N, device=dev), fw.to(dev), bw.to(dev)],
+            [size.to(dev).repeat(N, 1), torch.full((N, 1), nfr, device=dev)]]
+
+
+@pytest.mark.parametrize("tag", ["f2up", "f6up", "f3noup"])
+def test_apply_optical_flow_golden(dev, tag):
+    from contrast import util
+    g = load_golden(f"applyflow_{tag}")
+    fw, bw = g["flow_fwds"], g["flow_bwds"]
+    (f, s, mf), (b, _, mb) = util.apply_optical_flow(_data(fw, bw, g["size"], fw.shape[1] + 1, dev), None,
+                                                     _args(bool(g["flow_up"])))
+    assert torch.equal(f.cpu(), g["flow_fwd"]) and torch.equal(b.cpu(), g["flow_bwd"])
+    assert torch.equal(mf.cpu(), g["mask_fwd"]) and torch.equal(mb.cpu(), g["mask_bwd"])
+    assert torch.equal(s.cpu(), g["size"])
+    # counts carried by the fused launch == dense recount
+    r1 = util.calc_mask_ratio(mf).cpu()
+    r2 = (~g["mask_fwd"]).float().mean((-1, -2))
+    assert torch.allclose(r1, r2, atol=1e-6, rtol=0)
+
+
+@pytest.mark.parametrize("nfr,hw", [(2, (90, 160)), (6, (45, 80)), (3, (23, 37))])
+def test_apply_optical_flow_vs_oracle_full_size(dev, nfr, hw):
+    """BDD-sized (720x1280 for nframe 2) and ragged sizes against the oracle; flows bit-exact,
+    masks exact."""
+    from contrast import util
+    from oracle import pixpro_oracle as O
+    from recipes import smooth_flow
+    gen = torch.Generator().manual_seed(5 + nfr)
+    N = 2
+    fw = smooth_flow((N, nfr - 1, 2, *hw), 0.5, gen)
+    bw = -fw.flip(1) + smooth_flow((N, nfr - 1, 2, *hw), 0.05, gen)
+    size = torch.tensor([8 * hw[0], 8 * hw[1]])
+    (f, _, mf), (b, _, mb) = util.apply_optical_flow(_data(fw, bw, size, nfr, dev), None, _args(True))
+    (fo, _, mfo), (bo, _, mbo) = O.apply_optical_flow_file(fw, bw, size, True, 0.01, 0.5)
+    assert torch.equal(f.cpu(), fo) and torch.equal(b.cpu(), bo)
+    assert torch.equal(mf.cpu(), mfo) and torch.equal(mb.cpu(), mbo)
+    assert 0 < mfo.float().mean() < 1
+
+
+def test_apply_optical_flow_variants(dev):
+    """alpha None -> no masks; flow_cat_norm staged variant vs oracle."""
+    from contrast import util
+    from oracle import pixpro_oracle as O
+    from recipes import smooth_flow
+    gen = torch.Generator().manual_seed(9)
+    fw = smooth_flow((2, 2, 2, 12, 16), 0.5, gen)
+    bw = -fw.flip(1)
+    size = torch.tensor([96, 128])
+    (f, _, mf), _ = util.apply_optical_flow(_data(fw, bw, size, 3, dev), None, _args(True, alpha1=None, alpha2=None))
+    assert mf is None
+    (fo, _, _), _ = O.apply_optical_flow_file(fw, bw, size, True, None, None)
+    assert torch.equal(f.cpu(), fo)
+    (f, _, mf), (b, _, mb) = util.apply_optical_flow(_data(fw, bw, size, 3, dev), None, _args(True, flow_cat_norm=True))
+    (fo, _, mfo), (bo, _, mbo) = O.apply_optical_flow_file(fw, bw, size, True, 0.01, 0.5, flow_cat_norm=True)
+    assert torch.allclose(f.cpu(), fo, atol=1e-4) and torch.allclose(b.cpu(), bo, atol=1e-4)
+    assert (mf.cpu() != mfo).float().mean() < 1e-3
+
+
+def test_flow_properties_full_size(dev):
+    """Size-independent properties at BDD100k size: chain of zeros is zero; fbc(f,-f) for constant f is
+    valid exactly where x+f stays inside; single-flow chain is the identity."""
+    from contrast import util
+    z = torch.zeros(3, 1, 2, 720, 1280, device=dev)
+    assert util.concat_flow(z).abs().max().item() == 0
+    f = torch.full((1, 2, 720, 1280), 2.5, device=dev)
+    m = util.forward_backward_consistency(f, -f)[2][0]
+    inside = torch.zeros(720, 1280, dtype=torch.bool)
+    inside[:717, :1277] = True
+    assert torch.equal(m[0].cpu(), inside)
+    one = torch.randn(1, 2, 2, 64, 64, device=dev)
+    assert torch.equal(util.concat_flow(one), one[0])

@@ -1,0 +1,117 @@
+"""Model-level parity: BASELINE config 1 (ResNet-18, 64x64 crops, N=8, identity flow on a 320x180 frame)
+on the GPU vs the loss / pos_num / gradients captured from the reference's own PixPro on CPU; EMA and
+LARS multi-tensor kernels vs golden trajectories."""
+import json
+import os
+import types
+
+import pytest
+import torch
+
+from conftest import GOLDEN, load_golden
+from gpu_utils import close
+
+pytestmark = pytest.mark.gpu
+
+
+def cfg1_args(**kw):
+    base = dict(pixpro_p=2.0, pixpro_momentum=0.99, pixpro_pos_ratio=0.7, pixpro_clamp_value=0.0,
+                pixpro_transform_layer=1, pixpro_ins_loss_weight=0.0, output_dir="/tmp", num_instances=800,
+                batch_size=8, epochs=10, start_epoch=1, feature_dim=256, head_type="early_return", sync_bn=True)
+    base.update(kw)
+    return types.SimpleNamespace(**base)
+
+
+def test_model_cfg1_step(dev):
+    from contrast import resnet
+    from contrast.models import PixPro
+    from recipes import seeded_state_dict
+    g = load_golden("model_cfg1")
+    with open(os.path.join(GOLDEN, "model_cfg1_shapes.json")) as fh:
+        shapes = {k: tuple(v) for k, v in json.load(fh).items()}
+    model = PixPro(resnet.resnet18, cfg1_args())
+    mine = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    assert mine == shapes                                   # checkpoint-compatible names and shapes
+    model.load_state_dict(seeded_state_dict(shapes, 61))
+    model = model.to(dev).train()
+    Ho, Wo = 180, 320
+    zf = torch.zeros(8, 2, Ho, Wo, device=dev)
+    c1, c2 = g["coord1"].to(dev), g["coord2"].to(dev)
+    loss, pos = model(g["im1"].to(dev), g["im2"].to(dev), [c1, [zf, (Ho, Wo), None]], [c2, [zf, (Ho, Wo), None]])
+    loss.backward()
+    assert torch.equal(pos[0][0].cpu(), g["pos_num_1"]) and torch.equal(pos[1][0].cpu(), g["pos_num_2"])
+    assert abs(loss.item() - g["loss"]) <= 1e-4 * max(1.0, abs(g["loss"]))
+    named = dict(model.named_parameters())
+    for key in ("value_transform.weight", "value_transform.bias", "projector.linear2.bias"):
+        close(named[key].grad, g["grad:" + key], rel=2e-3)
+    for key in ("projector.linear2.weight", "encoder.conv1.weight", "encoder.layer4.1.conv2.weight"):
+        close(named[key].grad.flatten()[::97], g["gradslice:" + key], rel=5e-3)
+    sd = model.state_dict()
+    for key in ("projector_k.linear2.bias", "encoder_k.bn1.weight"):
+        assert torch.allclose(sd[key].cpu(), g["ema:" + key], rtol=1e-6, atol=1e-7)
+    assert model.k == g["momentum_k"] and model.K == g["momentum_K"]
+
+
+def test_ema_matches_oracle(dev):
+    from contrast.multi_tensor import ema_update
+    from oracle import pixpro_oracle as O
+    gen = torch.Generator().manual_seed(0)
+    shapes = [(64, 3, 7, 7), (64,), (1,), (4096, 37), (5,), (129, 3, 3, 3)]
+    pq = [torch.randn(*s, generator=gen) for s in shapes]
+    pk = [torch.randn(*s, generator=gen) for s in shapes]
+    m = O.momentum_coefficient(0.99, 123, 8750)
+    want = O.momentum_update(pq, pk, m)
+    dq = [t.to(dev) for t in pq]
+    dk = [t.to(dev) for t in pk]
+    # odd offsets exercise the unaligned path
+    ema_update(dq, dk, m)
+    for a, b in zip(dk, want):
+        assert torch.equal(a.cpu(), b)
+
+
+def test_lars_golden_trajectory(dev):
+    from contrast.lars import LARS, add_weight_decay
+    g = load_golden("lars")
+    n = g["n"]
+    model = torch.nn.Module()
+    params = []
+    for i in range(n):
+        p = torch.nn.Parameter(g[f"p0_{i}"].to(dev))
+        model.register_parameter(f"p{i}", p)
+        params.append(p)
+    opt = LARS(torch.optim.SGD(add_weight_decay(model, g["weight_decay"]), lr=g["lr"], momentum=g["momentum"]))
+    for s in range(3):
+        opt.zero_grad()
+        for i, p in enumerate(params):
+            p.grad = g[f"g{s}_{i}"].to(dev)
+        opt.step()
+        for i, p in enumerate(params):
+            assert torch.allclose(p.detach().cpu(), g[f"p{s + 1}_{i}"], rtol=2e-6, atol=1e-7), (s, i)
+
+
+def test_train_step_runs_and_learns(dev):
+    """Three synthetic steps of the main_pretrain step (flow prep + fused hot path + LARS + EMA): finite,
+    no exceptions, parameters and key encoder move."""
+    import main_pretrain
+    from contrast import option
+    from contrast.lr_scheduler import get_scheduler
+    from contrast.synthetic import make_batch
+    args = option.parse_option(argv=["--model", "PixPro", "--arch", "resnet18", "--synthetic", "--use_flow",
+                                     "--use_flow_file", "--flow_up", "--alpha1", "0.01", "--alpha2", "0.5",
+                                     "--n-frames", "3", "--optimizer", "lars", "--base-lr", "1.0",
+                                     "--weight-decay", "1e-5", "--amp-opt-level", "O0", "--pixpro-p", "2",
+                                     "--pixpro-transform-layer", "1", "--batch-size", "4", "--epochs", "2",
+                                     "--warmup-epoch", "0", "--head-type", "early_return"])
+    args.num_instances = 64
+    model, opt = main_pretrain.build_model(args, dev)
+    sched = get_scheduler(opt, 4, args)
+    model.train()
+    data = make_batch(4, image_size=64, n_frames=3, frame_hw=(96, 128), device=dev, sigma=0.5)
+    w0 = model.value_transform.weight.detach().clone()
+    k0 = model.projector_k.linear2.weight.detach().clone()
+    for _ in range(3):
+        loss, pos, info = main_pretrain.train_step(model, opt, sched, data, args)
+        assert torch.isfinite(loss).item()
+    assert not torch.equal(w0, model.value_transform.weight)
+    assert not torch.equal(k0, model.projector_k.linear2.weight)
+    assert info["mask_fwd"].dtype == torch.bool

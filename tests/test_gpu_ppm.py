@@ -1,0 +1,241 @@
+"""HIP PPM + pixel loss (fused MFMA kernel and staged generic path) vs golden vectors captured from the
+reference and vs the CPU oracle.  Tolerances: pos_num exact; loss abs 1e-5; pred abs
+2e-6; gradients 1e-4 of the reference's max-abs."""
+import random
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden
+from gpu_utils import close, to_dev
+
+pytestmark = pytest.mark.gpu
+
+REGLOSS = ["noflow7", "zeroflow7", "flowfull7", "flowmask7", "floweighth7", "flowbare14", "flowmask2", "c256"]
+
+
+def coord_args(g, dev):
+    mode = g["mode"]
+    cq, ck = g["coord_q"].to(dev), g["coord_k"].to(dev)
+    size = tuple(int(s) for s in g["size"])
+    mask = g["mask"].to(dev) if g["has_mask"] else None
+    flow = g["flow"].to(dev) if g["flow"].numel() else None
+    if mode == "none":
+        return cq, ck
+    if mode == "bare":
+        return [cq, flow], [ck, flow]
+    if mode == "eighth":
+        return [cq, [flow, torch.tensor(size, device=dev), mask]], [ck, [flow, size, mask]]
+    return [cq, [flow, size, mask]], [ck, [flow, size, mask]]
+
+
+@pytest.mark.parametrize("tag", REGLOSS)
+def test_regression_loss_golden(dev, tag):
+    from contrast.models.PixPro import regression_loss
+    g = load_golden(f"regloss_{tag}")
+    a, b = coord_args(g, dev)
+    q = g["q"].to(dev).requires_grad_(True)
+    loss, (pn, pm) = regression_loss(q, g["k"].to(dev), a, b, g["pos_ratio"])
+    loss.backward()
+    assert torch.equal(pn.cpu(), g["pos_num"])
+    assert torch.allclose(pm.cpu(), g["pos_mean"], rtol=1e-6, atol=0)
+    assert abs(loss.item() - g["loss"]) <= 1e-5
+    close(q.grad, g["dq"])
+
+
+@pytest.mark.parametrize("tag", [t for t in REGLOSS if t != "noflow7"])
+def test_add_optical_flow_bitwise(dev, tag):
+    from contrast.models.PixPro import add_optical_flow
+    g = load_golden(f"regloss_{tag}")
+    size = tuple(int(s) for s in g["size"])
+    mask = g["mask"].to(dev) if g["has_mask"] else None
+    ox, oy, mg = add_optical_flow(g["flow"].to(dev), g["aof_x_in"].to(dev), g["aof_y_in"].to(dev), size, mask)
+    assert torch.equal(ox.cpu(), g["aof_x"]) and torch.equal(oy.cpu(), g["aof_y"])
+    if mask is not None:
+        assert torch.equal(mg.cpu(), g["aof_mask"])
+
+
+@pytest.mark.parametrize("tag", ["p2", "p1", "p05", "g14", "g2"])
+def test_featprop_golden(dev, tag):
+    from contrast import ops
+    g = load_golden(f"featprop_{tag}")
+    C = g["x"].shape[1]
+    x = g["x"].to(dev).requires_grad_(True)
+    wv, bv = g["wv"].to(dev), g["bv"].to(dev)
+    v = F.conv2d(x, wv.view(C, C, 1, 1), bv) if g["layer"] == 1 else x
+    Y = ops.featprop(x, v, g["p"], g["clamp"])
+    pred = F.normalize(Y, dim=1)
+    (pred * g["gpred"].to(dev)).sum().backward()
+    assert (Y.detach().cpu() - g["Y"]).abs().max() <= 2e-6 * max(1.0, g["Y"].abs().max().item())
+    assert (pred.detach().cpu() - g["pred"]).abs().max() <= 2e-6
+    close(x.grad, g["dx_total"], rel=2e-4)
+
+
+def _hotpath(dev, g, generic):
+    from contrast import ops
+    C = g["x1"].shape[1]
+    x1 = g["x1"].to(dev).requires_grad_(True)
+    x2 = g["x2"].to(dev).requires_grad_(True)
+    wv = g["wv"].to(dev).requires_grad_(True)
+    bv = g["bv"].to(dev).requires_grad_(True)
+    size = tuple(int(s) for s in g["size"])
+    v1 = F.conv2d(x1, wv.view(C, C, 1, 1), bv)
+    v2 = F.conv2d(x2, wv.view(C, C, 1, 1), bv)
+    c1, c2 = g["coord1"].to(dev), g["coord2"].to(dev)
+    d1 = ops.Direction(x1, v1, g["k2"].to(dev), c1, c2, g["flow_fwd"].to(dev), g["mask_fwd"].to(dev), size)
+    d2 = ops.Direction(x2, v2, g["k1"].to(dev), c2, c1, g["flow_bwd"].to(dev), g["mask_bwd"].to(dev), size)
+    loss, pn, pm, ln, preds = ops.ppm_loss([d1, d2], g["p"], 0.0, 0.7, True, want_pred=True, generic=generic)
+    loss.backward()
+    return loss, pn, pm, preds, x1, x2, wv, bv
+
+
+@pytest.mark.parametrize("tag,generic", [("e2e7", False), ("e2e7", True), ("e2e14", True), ("e2e2", True)])
+def test_hotpath_golden(dev, tag, generic):
+    g = load_golden(f"hotpath_{tag}")
+    loss, pn, pm, preds, x1, x2, wv, bv = _hotpath(dev, g, generic)
+    assert torch.equal(pn[0].cpu(), g["pos_num_1"]) and torch.equal(pn[1].cpu(), g["pos_num_2"])
+    assert torch.allclose(pm[0].cpu(), g["pos_mean_1"], rtol=1e-6, atol=0)
+    assert abs(loss.item() - g["loss"]) <= 1e-5
+    assert (preds[0].cpu() - g["pred1"]).abs().max() <= 2e-6
+    assert (preds[1].cpu() - g["pred2"]).abs().max() <= 2e-6
+    close(x1.grad, g["dx1"]); close(x2.grad, g["dx2"]); close(wv.grad, g["dwv"]); close(bv.grad, g["dbv"])
+
+
+def _random_problem(dev, N, C, H, W, Ho, Wo, seed, eighth=False, sigma=4.0):
+    from recipes import crop_coords, smooth_flow
+    gen = torch.Generator().manual_seed(seed)
+    rng = random.Random(seed)
+    t = lambda: torch.randn(N, C, H, W, generator=gen)
+    x1, v1, x2, v2, k1, k2 = t(), t(), t(), t(), t(), t()
+    c1 = crop_coords(N, Wo, Ho, rng)
+    c2 = crop_coords(N, Wo, Ho, rng)
+    c2[: N // 2, :4] = c1[: N // 2, :4] + 0.02 * torch.randn(N // 2, 4, generator=gen)
+    fh, fw = (Ho // 8, Wo // 8) if eighth else (Ho, Wo)
+    ff = smooth_flow((N, 2, fh, fw), sigma, gen)
+    fb = -ff + smooth_flow((N, 2, fh, fw), 0.3, gen)
+    mf = torch.rand(N, fh, fw, generator=gen) > 0.2
+    mb = torch.rand(N, fh, fw, generator=gen) > 0.2
+    return dict(x1=x1, v1=v1, x2=x2, v2=v2, k1=k1, k2=k2, c1=c1, c2=c2, ff=ff, fb=fb, mf=mf, mb=mb, size=(Ho, Wo))
+
+
+def _run_hip(dev, P, p=2.0, clamp=0.0, generic=False, flow=True, mask=True, grad_scale=None, want_pred=False):
+    from contrast import ops
+    q = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in P.items()}
+    xs = [q[n].clone().requires_grad_(True) for n in ("x1", "v1", "x2", "v2")]
+    f = (lambda n: q[n]) if flow else (lambda n: None)
+    m = (lambda n: q[n]) if (flow and mask) else (lambda n: None)
+    size = q["size"] if flow else None
+    d1 = ops.Direction(xs[0], xs[1], q["k2"], q["c1"], q["c2"], f("ff"), m("mf"), size)
+    d2 = ops.Direction(xs[2], xs[3], q["k1"], q["c2"], q["c1"], f("fb"), m("mb"), size)
+    out = ops.ppm_loss([d1, d2], p, clamp, 0.7, True, want_pred=want_pred, generic=generic)
+    loss = out[0]
+    (loss if grad_scale is None else loss * grad_scale).backward()
+    return out, [t.grad for t in xs]
+
+
+def _run_oracle(P, p=2.0, clamp=0.0):
+    from oracle import pixpro_oracle as O
+    xs = [P[n].clone().requires_grad_(True) for n in ("x1", "v1", "x2", "v2")]
+    a = [P["c1"], [P["ff"], P["size"], P["mf"]]]
+    b = [P["c2"], [P["fb"], P["size"], P["mb"]]]
+    l1, p1, n1, m1 = O.ppm_loss(xs[0], xs[1], P["k2"], a, b, p, clamp, 0.7, True)
+    l2, p2, n2, m2 = O.ppm_loss(xs[2], xs[3], P["k1"], b, a, p, clamp, 0.7, True)
+    (l1 + l2).backward()
+    return (l1 + l2).item(), torch.stack([n1, n2]), [t.grad for t in xs], (p1, p2)
+
+
+@pytest.mark.parametrize("shape,generic,p,clamp", [
+    ((6, 256, 7, 7), False, 2.0, 0.0), ((5, 128, 7, 7), False, 2.0, 0.0), ((6, 256, 7, 7), False, 1.0, 0.0),
+    ((4, 256, 7, 7), False, 0.5, 0.1), ((4, 256, 7, 7), False, 3.0, 0.2), ((8, 256, 2, 2), False, 2.0, 0.0),
+    ((3, 256, 8, 8), False, 2.0, 0.0), ((3, 128, 5, 6), False, 2.0, 0.0), ((2, 256, 1, 1), False, 2.0, 0.0),
+    ((3, 256, 7, 7), True, 2.0, 0.0), ((2, 64, 14, 14), True, 2.0, 0.0), ((3, 48, 3, 5), True, 0.5, 0.1),
+    ((1, 256, 14, 14), True, 2.0, 0.0),
+])
+def test_ppm_loss_vs_oracle(dev, shape, generic, p, clamp):
+    N, C, H, W = shape
+    P = _random_problem(dev, N, C, H, W, 48, 64, seed=N * 1000 + C + H)
+    lo, pno, go, (p1, p2) = _run_oracle(P, p, clamp)
+    out, gh = _run_hip(dev, P, p, clamp, generic, want_pred=True)
+    assert torch.equal(out[1].cpu(), pno)
+    assert abs(out[0].item() - lo) <= 1e-5 * max(1.0, abs(lo))
+    assert (out[4][0].cpu() - p1).abs().max() <= 2e-6
+    assert pno.sum() > 0
+    for a, b in zip(gh, go):
+        close(a, b)
+
+
+def test_eighth_res_flow_and_device_size(dev):
+    """flow at 1/8 resolution of the frame (ratio branch of add_optical_flow) with the frame size given as
+    a device tensor (no host sync) and as a tuple."""
+    from contrast import ops
+    P = _random_problem(dev, 6, 256, 7, 7, 384, 512, seed=77, eighth=True, sigma=2.0)
+    lo, pno, go, _ = _run_oracle(P)
+    out, gh = _run_hip(dev, P)
+    assert torch.equal(out[1].cpu(), pno) and abs(out[0].item() - lo) <= 1e-5
+    P2 = dict(P)
+    P2["size"] = torch.tensor([384, 512], device=dev)
+    out2, _ = _run_hip(dev, P2)
+    assert torch.equal(out2[1], out[1]) and out2[0].item() == out[0].item()
+
+
+def test_fused_equals_generic_full_batch(dev):
+    """BASELINE config 2 size (N=256, 7x7, C=256): MFMA kernel vs the staged path, run on the device."""
+    P = _random_problem(dev, 256, 256, 7, 7, 90, 160, seed=3)
+    of, gf = _run_hip(dev, P, generic=False)
+    og, gg = _run_hip(dev, P, generic=True)
+    assert torch.equal(of[1], og[1]) and torch.equal(of[2], og[2])
+    assert abs(of[0].item() - og[0].item()) <= 1e-5
+    assert torch.allclose(of[3], og[3], atol=1e-6)
+    for a, b in zip(gf, gg):
+        close(a, b)
+
+
+def test_properties_full_batch(dev):
+    """Size-independent properties at N=256: zero flow == no flow; all-true mask == no
+    mask; all-false mask -> pos_num 0, loss 0, grads 0; gradients scale linearly with the upstream."""
+    P = _random_problem(dev, 256, 256, 7, 7, 90, 160, seed=4)
+    Pz = dict(P, ff=torch.zeros_like(P["ff"]), fb=torch.zeros_like(P["fb"]))
+    a, ga = _run_hip(dev, Pz, mask=False)
+    b, gb = _run_hip(dev, Pz, flow=False)         # frame size read from coord[0][9], [0][8] on the device
+    assert torch.equal(a[1], b[1]) and a[0].item() == b[0].item()
+    for u, v in zip(ga, gb):
+        assert torch.equal(u, v)
+    c, gc = _run_hip(dev, P, mask=False)
+    Pt = dict(P, mf=torch.ones_like(P["mf"]), mb=torch.ones_like(P["mb"]))
+    d, gd = _run_hip(dev, Pt)
+    assert torch.equal(c[1], d[1]) and c[0].item() == d[0].item()
+    Pf = dict(P, mf=torch.zeros_like(P["mf"]), mb=torch.zeros_like(P["mb"]))
+    e, ge = _run_hip(dev, Pf)
+    assert e[1].sum().item() == 0 and e[0].item() == 0.0
+    assert all(t.abs().max().item() == 0 for t in ge)
+    f, gf = _run_hip(dev, P, grad_scale=3.0)
+    h, gh = _run_hip(dev, P)
+    for u, v in zip(gf, gh):
+        assert torch.allclose(u, 3.0 * v, rtol=1e-6, atol=1e-12)
+
+
+def test_pos_ratio_infinite_mean_logit(dev):
+    """pos_ratio -> inf, no mask => M == 1 and loss = -2*mean_n(mean_ij q_i.k_j) (property 3)."""
+    from contrast.models.PixPro import regression_loss
+    gen = torch.Generator().manual_seed(1)
+    q = F.normalize(torch.randn(5, 64, 7, 7, generator=gen), dim=1).to(dev)
+    k = F.normalize(torch.randn(5, 64, 7, 7, generator=gen), dim=1).to(dev)
+    from recipes import crop_coords
+    c = crop_coords(5, 320, 180, random.Random(2)).to(dev)
+    loss, (pn, pm) = regression_loss(q, k, c, c, 1e30)
+    ref = -2 * torch.einsum("ncp,ncr->npr", q.flatten(2), k.flatten(2)).mean((1, 2)).mean()
+    assert pn.eq(49 * 49).all() and abs(loss.item() - ref.item()) <= 1e-6
+
+
+def test_rejects_cpu_and_bad_shapes(dev):
+    from contrast import ops
+    from contrast.models.PixPro import regression_loss
+    q = torch.randn(2, 8, 2, 2)
+    c = torch.rand(2, 10)
+    with pytest.raises(RuntimeError, match="GPU only"):
+        regression_loss(q, q, c, c, 0.7)
+    with pytest.raises(RuntimeError, match="expected shape"):
+        regression_loss(q.to(dev), q.to(dev), c.to(dev)[:1], c.to(dev), 0.7)
+    with pytest.raises(RuntimeError, match="mask given without flow"):
+        ops.regression_loss_op(q.to(dev), q.to(dev), c.to(dev), c.to(dev), 0.7, None, torch.ones(2, 4, 4, dtype=torch.bool, device=dev))
