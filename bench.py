@@ -1,0 +1,242 @@
+#!/usr/bin/env python
+"""bench.py --gpus N --steps K --warmup W
+
+Measures BASELINE.json's metric: pre-train images/sec (whole node) of the ResNet-50 PixPro+optical-flow
+step at 224x224, nframe=2, fp32 (the flow recipes train at apex O0), synthetic inputs resident in HBM.
+A step = file-mode flow preparation (HIP) -> 2 online + 2 momentum encoder passes (PyTorch-ROCm) ->
+fused PPM / flow-matched pixel loss forward+backward (HIP) -> backward -> LARS step (HIP) -> LR schedule;
+the EMA of the key encoder (HIP) runs inside the forward as in the reference.
+
+For N>1 the driver starts one process per GPU (torch.distributed.run); gradients are all-reduced by DDP over
+RCCL/xGMI and BatchNorm statistics by SyncBN.  Per-GPU batch is fixed (weak scaling).  Rank 0 prints one
+JSON line; besides the contract keys it carries
+  roofline      dominant hot-path kernel: algorithmic bytes / HIP-event duration measured inside the timed steps
+  hot_kernels   the same for every hot-path kernel of the step
+  cpu_baseline  the CPU oracle (port of the reference's torch-CPU path) timed on this host on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "pixpro-with-opticalflow_amd"))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK = 8.0e12        # B/s, MI355X_MICROARCH.md
+MFMA_F32_PEAK = 157.3e12  # FLOP/s, MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (BASELINE configs[1]: 256 on 1 GPU)")
+    ap.add_argument("--image-size", type=int, default=224)
+    ap.add_argument("--n-frames", type=int, default=2)
+    ap.add_argument("--arch", default="resnet50")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-flow-images", type=int, default=8)
+    ap.add_argument("--channels-last", action="store_true")
+    return ap.parse_args()
+
+
+def note(rank, msg):
+    if rank == 0:
+        print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+
+def model_args(a, world):
+    from contrast import option
+    argv = ["--model", "PixPro", "--arch", a.arch, "--synthetic", "--use_flow", "--use_flow_file", "--flow_up",
+            "--alpha1", "0.01", "--alpha2", "0.5", "--n-frames", str(a.n_frames), "--optimizer", "lars",
+            "--base-lr", "1.0", "--weight-decay", "1e-5", "--amp-opt-level", "O0", "--pixpro-p", "2",
+            "--pixpro-transform-layer", "1", "--pixpro-pos-ratio", "0.7", "--batch-size", str(a.batch),
+            "--epochs", "2000", "--warmup-epoch", "5", "--head-type", "early_return",
+            "--image-size", str(a.image_size), str(a.image_size)]
+    if a.channels_last:
+        argv.append("--channels-last")
+    args = option.parse_option(argv=argv)
+    args.num_instances = 70000
+    return args
+
+
+class KernelClock:
+    """HIP-event pairs recorded on the launch stream around hot-path calls inside the timed steps."""
+
+    def __init__(self):
+        self.pairs = {}
+
+    def wrap(self, name, fn):
+        def timed(*a, **k):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            out = fn(*a, **k)
+            e.record()
+            self.pairs.setdefault(name, []).append((s, e))
+            return out
+        return timed
+
+    def reset(self):
+        self.pairs = {}
+
+    def mean_ms(self):
+        return {k: sum(s.elapsed_time(e) for s, e in v) / len(v) for k, v in self.pairs.items()}
+
+
+def cpu_baseline(a, args):
+    """The oracle on the host cores: file-mode flow preparation for `cpu_flow_images` images at 720x1280 and
+    PPM+loss forward+backward for one full batch; reported as hot-path images/s."""
+    from oracle import pixpro_oracle as O
+    from contrast.synthetic import make_batch
+    torch.set_num_threads(os.cpu_count())
+    nf = a.cpu_flow_images
+    data = make_batch(nf, image_size=8, n_frames=a.n_frames, device="cpu", seed=99)
+    _, lo_f, lo_b = data[5]
+    size = (720, 1280)
+    t0 = time.perf_counter()
+    ff, fb = O.apply_optical_flow_file(lo_f, lo_b, size, True, 0.01, 0.5)
+    t_flow = (time.perf_counter() - t0) / nf
+    N, C, G = a.batch, 256, a.image_size // 32
+    gen = torch.Generator().manual_seed(5)
+    big = make_batch(N, image_size=8, n_frames=2, device="cpu", seed=98, with_flow=False)
+    c1, c2 = big[2], big[3]
+    flow_f = ff[0][:1].expand(N, -1, -1, -1)
+    flow_b = fb[0][:1].expand(N, -1, -1, -1)
+    mask_f = ff[2][:1].expand(N, -1, -1)
+    mask_b = fb[2][:1].expand(N, -1, -1)
+    xs = [torch.randn(N, C, G, G, generator=gen).requires_grad_(True) for _ in range(4)]
+    ks = [torch.randn(N, C, G, G, generator=gen) for _ in range(2)]
+    reps, t_ppm = 0, 0.0
+    while t_ppm < 3.0 and reps < 20:
+        t0 = time.perf_counter()
+        A = [c1, [flow_f, size, mask_f]]
+        B = [c2, [flow_b, size, mask_b]]
+        l1 = O.ppm_loss(xs[0], xs[1], ks[1], A, B, 2.0, 0.0, 0.7, True)[0]
+        l2 = O.ppm_loss(xs[2], xs[3], ks[0], B, A, 2.0, 0.0, 0.7, True)[0]
+        (l1 + l2).backward()
+        t_ppm += time.perf_counter() - t0
+        reps += 1
+    t_ppm = t_ppm / reps / N
+    return {"value": round(1.0 / (t_flow + t_ppm), 2), "unit": "images/s (hot path only: flow prep + PPM/loss fwd+bwd)",
+            "cores": os.cpu_count(), "kind": "port",
+            "sample": f"oracle/pixpro_oracle.py, torch-CPU fp32, {os.cpu_count()} threads: flow prep nframe={a.n_frames} "
+                      f"720x1280 on {nf} images ({t_flow * 1e3:.1f} ms/img) + PPM/loss fwd+bwd on {N} images x{reps} "
+                      f"({t_ppm * 1e3:.3f} ms/img); encoders excluded",
+            "flow_ms_per_image": round(t_flow * 1e3, 3), "ppm_ms_per_image": round(t_ppm * 1e3, 4)}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group(backend="nccl", init_method="env://")   # RCCL
+    import main_pretrain
+    from contrast import ops, util
+    from contrast.lr_scheduler import get_scheduler
+    from contrast.synthetic import SyntheticLoader
+
+    args = model_args(a, world)
+    # MIOpen immediate mode: this image ships no gfx950 find-db, and an exhaustive find on a fresh box
+    # compiles for many minutes; the heuristic picks the prebuilt CK implicit-GEMM kernels at once
+    torch.backends.cudnn.benchmark = bool(int(os.environ.get("PIXPRO_MIOPEN_FIND", "0")))
+    torch.manual_seed(1234 + rank)
+    loader = SyntheticLoader(a.steps + a.warmup, a.batch, pool=2, image_size=a.image_size, n_frames=a.n_frames,
+                             frame_hw=(720, 1280), device=dev, seed=1234 + rank)
+    model, optimizer = main_pretrain.build_model(args, dev)
+    scheduler = get_scheduler(optimizer, 70000 // (a.batch * world), args)
+    model.train()
+
+    clock = KernelClock()
+    util.apply_optical_flow = clock.wrap("flow_prepare", util.apply_optical_flow)
+    ops.ppm_loss = clock.wrap("ppm_loss", ops.ppm_loss)
+
+    it = iter(loader)
+    note(rank, f"model built ({a.arch}, per-GPU batch {a.batch}); warm-up")
+    for i in range(a.warmup):
+        tw = time.perf_counter()
+        loss, _, _ = main_pretrain.train_step(model, optimizer, scheduler, next(it), args)
+        torch.cuda.synchronize()
+        note(rank, f"warm-up step {i}: {time.perf_counter() - tw:.2f} s")
+    torch.cuda.synchronize()
+    clock.reset()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss, _, _ = main_pretrain.train_step(model, optimizer, scheduler, next(it), args)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    final_loss = loss.item()
+    ms = clock.mean_ms()
+    note(rank, f"timed {a.steps} steps in {elapsed:.2f} s; hot kernels (ms): {ms}")
+
+    if rank == 0:
+        P = (a.image_size // 32) ** 2
+        C = 256
+        A = 720 * 1280 * 4
+        F1 = a.n_frames - 1
+        # algorithmic bytes per image: dense flow prep B_flow; PPM+loss 10*C*P*4; flops 24*C*P^2
+        b_flow = (2 * F1 * 2 * A / 64 + 2 * F1 * 2 * A * 2 + 4 * A + A / 2)
+        b_ppm, f_ppm = 10 * C * P * 4, 24 * C * P * P
+        kernels = {}
+        if "flow_prepare" in ms:
+            t = ms["flow_prepare"] * 1e-3
+            kernels["flow_prepare"] = {"bound": "hbm", "achieved": round(b_flow * a.batch / t / 1e9, 1), "peak": HBM_PEAK / 1e9,
+                                       "unit": "GB/s", "frac": round(b_flow * a.batch / t / HBM_PEAK, 4), "traffic": None,
+                                       "ms_per_launch": round(ms["flow_prepare"], 4),
+                                       "algorithmic_bytes_per_launch": int(b_flow * a.batch)}
+        if "ppm_loss" in ms:
+            t = ms["ppm_loss"] * 1e-3
+            kernels["ppm_loss"] = {"bound": "mfma", "achieved": round(f_ppm * a.batch / t / 1e12, 3),
+                                   "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
+                                   "frac": round(f_ppm * a.batch / t / MFMA_F32_PEAK, 4), "traffic": None,
+                                   "ms_per_launch": round(ms["ppm_loss"], 4),
+                                   "algorithmic_flops_per_launch": int(f_ppm * a.batch),
+                                   "hbm_frac": round(b_ppm * a.batch / t / HBM_PEAK, 4)}
+        dominant = max(kernels, key=lambda k: kernels[k]["ms_per_launch"]) if kernels else None
+        out = {
+            "metric": f"pretrain images/sec (whole node), ResNet-50 PixPro+OF {a.image_size}^2, nframe={a.n_frames}",
+            "value": round(a.batch * world * a.steps / elapsed, 2), "unit": "images/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{a.arch} PixPro+optical-flow pre-train step, {a.image_size}x{a.image_size} crops, "
+                                   f"nframe={a.n_frames}, 720x1280 frames, file-mode flow (flow_up, alpha1=0.01, alpha2=0.5), "
+                                   f"p=2, transform_layer=1, LARS, fp32",
+                       "per_gpu_batch": a.batch, "global_batch": a.batch * world,
+                       "parallelism": f"dp{world}" if world > 1 else "single", "final_loss": round(final_loss, 5)},
+            "roofline": dict(kernel=dominant, **kernels[dominant]) if dominant else None,
+            "hot_kernels": kernels,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            note(rank, "timing the CPU oracle on a bounded sample")
+            cb = cpu_baseline(a, args)
+            out["cpu_baseline"] = cb
+            hot_ms = sum(ms.values())
+            out["hot_path_gpu"] = {"images_per_s": round(a.batch / (hot_ms * 1e-3), 1),
+                                   "ms_per_batch_fwd": round(hot_ms, 4),
+                                   "note": "flow prep + fused PPM/loss fwd+bwd on the GPU, same unit as cpu_baseline"}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

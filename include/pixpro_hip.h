@@ -78,7 +78,8 @@ const char* pixpro_last_error(void);
  * (PixPro.py:247,431).  Gradients (if dx != NULL) are d(grad_scale*loss)/dx, /dv.
  * Uses the single-launch MFMA kernel when P<=64 and C%128==0 (C<=256), otherwise the
  * staged generic path (needs workspace). */
-size_t pixpro_ppm_loss_workspace_bytes(const pixpro_problem* pb);
+size_t pixpro_ppm_loss_workspace_bytes(const pixpro_problem* pb);          /* 0 when the MFMA kernel applies */
+size_t pixpro_ppm_loss_generic_workspace_bytes(const pixpro_problem* pb);  /* staged path, any shape */
 int pixpro_ppm_loss(const pixpro_problem* pb, const pixpro_dir* dirs, float* loss_n,
                     float* pos_num, float* pos_mean, float* loss, void* workspace,
                     size_t workspace_bytes, void* stream);

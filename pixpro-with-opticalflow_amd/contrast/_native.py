@@ -39,6 +39,7 @@ SIGNATURES = {
     "pixpro_version": (ctypes.c_int, []),
     "pixpro_last_error": (ctypes.c_char_p, []),
     "pixpro_ppm_loss_workspace_bytes": (_sz, [_PP]),
+    "pixpro_ppm_loss_generic_workspace_bytes": (_sz, [_PP]),
     "pixpro_ppm_loss": (ctypes.c_int, [_PP, _DP, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "pixpro_ppm_loss_generic": (ctypes.c_int, [_PP, _DP, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "pixpro_scale_by_device_scalar": (ctypes.c_int, [_vp, _sz, _vp, _vp]),

@@ -104,9 +104,9 @@ class _PPMLoss(torch.autograd.Function):
             if want_pred:
                 cds[i].pred = nv.ptr(preds[i])
         lib = nv.load()
-        ws_bytes = lib.pixpro_ppm_loss_workspace_bytes(ctypes.byref(pb))
-        fused = (not generic) and pb.H * pb.W <= 64 and pb.C in (128, 256)
-        ws = None if fused else nv.workspace(ws_bytes, dev)
+        query = lib.pixpro_ppm_loss_generic_workspace_bytes if generic else lib.pixpro_ppm_loss_workspace_bytes
+        ws_bytes = query(ctypes.byref(pb))
+        ws = nv.workspace(ws_bytes, dev) if ws_bytes else None   # 0: the single-launch MFMA kernel applies
         nv.call("pixpro_ppm_loss_generic" if generic else "pixpro_ppm_loss", ctypes.byref(pb), cds,
                 nv.ptr(loss_n), nv.ptr(pos_num), nv.ptr(pos_mean), nv.ptr(loss), nv.ptr(ws),
                 0 if ws is None else ws.numel(), nv.stream())

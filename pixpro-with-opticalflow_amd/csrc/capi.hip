@@ -87,6 +87,11 @@ int pixpro_version(void) { return 100; }
 const char* pixpro_last_error(void) { return g_err; }
 
 size_t pixpro_ppm_loss_workspace_bytes(const pixpro_problem* pb) {
+  if (!pb || fused_supported(*pb)) return 0;
+  return generic_workspace_bytes(*pb);
+}
+
+size_t pixpro_ppm_loss_generic_workspace_bytes(const pixpro_problem* pb) {
   if (!pb) return 0;
   return generic_workspace_bytes(*pb);
 }

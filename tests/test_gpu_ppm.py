@@ -110,7 +110,8 @@ def _random_problem(dev, N, C, H, W, Ho, Wo, seed, eighth=False, sigma=4.0):
     x1, v1, x2, v2, k1, k2 = t(), t(), t(), t(), t(), t()
     c1 = crop_coords(N, Wo, Ho, rng)
     c2 = crop_coords(N, Wo, Ho, rng)
-    c2[: N // 2, :4] = c1[: N // 2, :4] + 0.02 * torch.randn(N // 2, 4, generator=gen)
+    # overlapping crops; kept inside the frame so that an all-True mask is equivalent to no mask
+    c2[: N // 2, :4] = (c1[: N // 2, :4] + 0.02 * torch.randn(N // 2, 4, generator=gen)).clamp(0, 1)
     fh, fw = (Ho // 8, Wo // 8) if eighth else (Ho, Wo)
     ff = smooth_flow((N, 2, fh, fw), sigma, gen)
     fb = -ff + smooth_flow((N, 2, fh, fw), 0.3, gen)
