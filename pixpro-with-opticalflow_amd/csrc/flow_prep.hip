@@ -207,6 +207,187 @@ __global__ void k_prepare_single(Source sf, Source sb, float* __restrict__ flow_
   }
 }
 
+// ---- production form of the above: flow_up, F-1 == 1 ----------------------------------------
+// Same arithmetic, restructured for instruction count (the generic kernel is VALU-bound):
+//   * 2-D tiles of 256 x 4 pixels, 4 consecutive pixels per thread -> no integer division for
+//     indexing, 16-B flow stores and 4-B mask stores;
+//   * divisions by the per-launch constants (Wf-1), (Hf-1) as q0 = a*r, q = fma(fma(-q0,b,a), r, q0)
+//     with r = RN(1/b): the correctly rounded quotient (Markstein), 3 instructions instead of ~10;
+//   * a pixel whose displaced position leaves the frame is invalid whatever the cycle error, so its
+//     taps are skipped; inside the frame all four taps are in range and share two x- and two y-axes
+//     of the lazy x8 up-sampling.
+struct DivC {
+  float b, rb;
+};
+inline DivC make_divc(float b) { return DivC{b, (float)(1.0 / (double)b)}; }
+__device__ __forceinline__ float div_c(float a, const DivC& d) {
+  const float q0 = a * d.rb;
+  const float rem = __builtin_fmaf(-q0, d.b, a);
+  return __builtin_fmaf(rem, d.rb, q0);
+}
+
+struct Up8Geom {
+  int h, w, Hf, Wf;
+  float sy, sx;      // (h-1)/(8h-1), (w-1)/(8w-1)
+  DivC wd, ht;       // Wf-1, Hf-1
+  float hx, hy;      // (Wf-1)/2, (Hf-1)/2
+  float alpha1, a2;
+};
+
+// Block-local LDS window over the four low-res channels {fwd.x, fwd.y, bwd.x, bwd.y}, one float4 per
+// low-res cell, replicate-padded (index clamping reproduces upflow8's edge clamps exactly).  It covers the
+// block's own footprint plus a margin of >= 6 low-res cells (~48 full-res pixels of displacement); taps that
+// fall outside it read global memory instead.
+constexpr int PT_X = 64, PT_Y = 4, PPX = 4;   // 64 x 4 threads, 4 pixels per thread along x
+constexpr int WIN_W = 48, WIN_H = 16, WIN_MX = 7, WIN_MY = 6;
+
+__shared__ float4 win_cells[WIN_H * WIN_W];   // file scope keeps the LDS address space (ds_read, not flat)
+
+struct Win {
+  int wx0, wy0;          // low-res coordinates of cell (0,0)
+  const float* g[4];     // global fallback: fwd.x, fwd.y, bwd.x, bwd.y
+  int h, w;
+};
+
+// the 2x2 low-res neighbourhood (i0y..i0y+1) x (i0x..i0x+1), clamped at the borders, all four channels
+__device__ __forceinline__ void lo_quad(const Win& wn, int i0y, int i0x, float4& a, float4& b, float4& c, float4& d) {
+  const int ry = i0y - wn.wy0, rx = i0x - wn.wx0;
+  if (__builtin_expect((unsigned)ry < (unsigned)(WIN_H - 1) && (unsigned)rx < (unsigned)(WIN_W - 1), 1)) {
+    const int o = ry * WIN_W + rx;
+    a = win_cells[o]; b = win_cells[o + 1]; c = win_cells[o + WIN_W]; d = win_cells[o + WIN_W + 1];
+  } else {
+    const int x1 = min(i0x + 1, wn.w - 1), y1 = min(i0y + 1, wn.h - 1);
+    const unsigned o00 = i0y * wn.w + i0x, o01 = i0y * wn.w + x1, o10 = y1 * wn.w + i0x, o11 = y1 * wn.w + x1;
+    a = make_float4(wn.g[0][o00], wn.g[1][o00], wn.g[2][o00], wn.g[3][o00]);
+    b = make_float4(wn.g[0][o01], wn.g[1][o01], wn.g[2][o01], wn.g[3][o01]);
+    c = make_float4(wn.g[0][o10], wn.g[1][o10], wn.g[2][o10], wn.g[3][o10]);
+    d = make_float4(wn.g[0][o11], wn.g[1][o11], wn.g[2][o11], wn.g[3][o11]);
+  }
+}
+
+// 16 * (weighted sum) = 2 * upflow8 value: both scalings are exact
+__device__ __forceinline__ float up8_x16(float a, float b, float c, float d, float w00, float w01, float w10, float w11) {
+  float acc = b * w01;
+  acc = __builtin_fmaf(a, w00, acc);
+  acc = __builtin_fmaf(c, w10, acc);
+  acc = __builtin_fmaf(d, w11, acc);
+  return 16.f * acc;
+}
+
+// validity of one pixel given its own flow (fx, fy); `opp` selects the opposite direction's channels
+// (0: fwd = .x/.y of the cell, 1: bwd = .z/.w)
+__device__ __forceinline__ bool fbc_up8(float fx, float fy, const Win& wn, int opp, const Up8Geom& g, float c0x,
+                                        float c0y) {
+  const float fnx = div_c(2.f * fx, g.wd), fny = div_c(2.f * fy, g.ht);
+  const float c1x = c0x + fnx, c1y = c0y + fny;
+  if (!((fabsf(c1x) < 1.f) && (fabsf(c1y) < 1.f))) return false;
+  const float ix = (c1x + 1.f) * g.hx, iy = (c1y + 1.f) * g.hy;
+  const float xw = floorf(ix), yn = floorf(iy);
+  const float w = ix - xw, e = 1.f - w, n = iy - yn, s = 1.f - n;
+  const int x0 = (int)xw, y0 = (int)yn;
+  const bool vx1 = x0 + 1 < g.Wf, vy1 = y0 + 1 < g.Hf;      // false only when the weight is exactly 0
+  const Up8Axis ax0 = up8_axis(x0, g.w, g.sx), ax1 = up8_axis(min(x0 + 1, g.Wf - 1), g.w, g.sx);
+  const Up8Axis ay0 = up8_axis(y0, g.h, g.sy), ay1 = up8_axis(min(y0 + 1, g.Hf - 1), g.h, g.sy);
+  float tx[4], ty[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const Up8Axis& ay = (t & 2) ? ay1 : ay0;
+    const Up8Axis& ax = (t & 1) ? ax1 : ax0;
+    const float w00 = ay.l0 * ax.l0, w01 = ay.l0 * ax.l1, w10 = ay.l1 * ax.l0, w11 = ay.l1 * ax.l1;
+    float4 a, b, c, d;
+    lo_quad(wn, ay.i0, ax.i0, a, b, c, d);
+    const bool ok = ((t & 1) ? vx1 : true) && ((t & 2) ? vy1 : true);
+    const float vx = div_c(opp ? up8_x16(a.z, b.z, c.z, d.z, w00, w01, w10, w11)
+                               : up8_x16(a.x, b.x, c.x, d.x, w00, w01, w10, w11), g.wd);
+    const float vy = div_c(opp ? up8_x16(a.w, b.w, c.w, d.w, w00, w01, w10, w11)
+                               : up8_x16(a.y, b.y, c.y, d.y, w00, w01, w10, w11), g.ht);
+    tx[t] = ok ? vx : 0.f;
+    ty[t] = ok ? vy : 0.f;
+  }
+  const float nw = s * e, ne = s * w, sw = n * e, se = n * w;
+  const float bx = __builtin_fmaf(tx[3], se, __builtin_fmaf(tx[2], sw, __builtin_fmaf(tx[1], ne, tx[0] * nw)));
+  const float by = __builtin_fmaf(ty[3], se, __builtin_fmaf(ty[2], sw, __builtin_fmaf(ty[1], ne, ty[0] * nw)));
+  const float cx = fnx + bx, cy = fny + by;
+  const float cyc = cx * cx + cy * cy;
+  const float eps = g.alpha1 * ((fnx * fnx + fny * fny) + (bx * bx + by * by)) + g.a2;
+  return (cyc - eps) <= 0.f;
+}
+
+__global__ void __launch_bounds__(PT_X* PT_Y)
+k_prepare_up8(const float* __restrict__ lo_fwd, const float* __restrict__ lo_bwd, float* __restrict__ flow_fwd,
+              float* __restrict__ flow_bwd, uint8_t* __restrict__ mask_fwd, uint8_t* __restrict__ mask_bwd,
+              int32_t* __restrict__ invalid, int N, Up8Geom g) {
+  const int n = blockIdx.z;
+  const int y = blockIdx.y * PT_Y + threadIdx.y;
+  const int xb = (blockIdx.x * PT_X + threadIdx.x) * PPX;
+  const size_t hw = (size_t)g.h * g.w, HW = (size_t)g.Hf * g.Wf;
+  Win wn;
+  wn.g[0] = lo_fwd + (size_t)n * 2 * hw; wn.g[1] = wn.g[0] + hw;
+  wn.g[2] = lo_bwd + (size_t)n * 2 * hw; wn.g[3] = wn.g[2] + hw;
+  wn.h = g.h; wn.w = g.w;
+  wn.wx0 = up8_axis(blockIdx.x * PT_X * PPX, g.w, g.sx).i0 - WIN_MX;
+  wn.wy0 = up8_axis(blockIdx.y * PT_Y, g.h, g.sy).i0 - WIN_MY;
+  for (int e = threadIdx.y * PT_X + threadIdx.x; e < WIN_H * WIN_W; e += PT_X * PT_Y) {
+    const int r = e / WIN_W, c = e % WIN_W;
+    const unsigned o = min(max(wn.wy0 + r, 0), g.h - 1) * g.w + min(max(wn.wx0 + c, 0), g.w - 1);
+    win_cells[e] = make_float4(wn.g[0][o], wn.g[1][o], wn.g[2][o], wn.g[3][o]);
+  }
+  __syncthreads();
+  int badf = 0, badb = 0;
+  if (y < g.Hf && xb < g.Wf) {
+    const Up8Axis ay = up8_axis(y, g.h, g.sy);
+    const float c0y = div_c(2.f * (float)y, g.ht) - 1.f;
+    float ffx[PPX], ffy[PPX], fbx[PPX], fby[PPX];
+    uint8_t mf[PPX], mb[PPX];
+#pragma unroll
+    for (int i = 0; i < PPX; ++i) {
+      const int x = min(xb + i, g.Wf - 1);
+      const Up8Axis ax = up8_axis(x, g.w, g.sx);
+      const float w00 = ay.l0 * ax.l0, w01 = ay.l0 * ax.l1, w10 = ay.l1 * ax.l0, w11 = ay.l1 * ax.l1;
+      float4 a, b, c, d;
+      lo_quad(wn, ay.i0, ax.i0, a, b, c, d);
+      const float fx = 0.5f * up8_x16(a.x, b.x, c.x, d.x, w00, w01, w10, w11);
+      const float fy = 0.5f * up8_x16(a.y, b.y, c.y, d.y, w00, w01, w10, w11);
+      const float bx = 0.5f * up8_x16(a.z, b.z, c.z, d.z, w00, w01, w10, w11);
+      const float by = 0.5f * up8_x16(a.w, b.w, c.w, d.w, w00, w01, w10, w11);
+      ffx[i] = fx; ffy[i] = fy; fbx[i] = bx; fby[i] = by;
+      mf[i] = mb[i] = 0;
+      if (mask_fwd) {
+        const float c0x = div_c(2.f * (float)x, g.wd) - 1.f;
+        mf[i] = fbc_up8(fx, fy, wn, 1, g, c0x, c0y) ? 1 : 0;
+        mb[i] = fbc_up8(bx, by, wn, 0, g, c0x, c0y) ? 1 : 0;
+        if (xb + i < g.Wf) { badf += 1 - mf[i]; badb += 1 - mb[i]; }
+      }
+    }
+    const size_t r = (size_t)y * g.Wf + xb;
+    float* pf = flow_fwd + (size_t)n * 2 * HW + r;
+    float* pb = flow_bwd + (size_t)n * 2 * HW + r;
+    if (xb + PPX <= g.Wf && (g.Wf & 3) == 0) {
+      *reinterpret_cast<float4*>(pf) = make_float4(ffx[0], ffx[1], ffx[2], ffx[3]);
+      *reinterpret_cast<float4*>(pf + HW) = make_float4(ffy[0], ffy[1], ffy[2], ffy[3]);
+      *reinterpret_cast<float4*>(pb) = make_float4(fbx[0], fbx[1], fbx[2], fbx[3]);
+      *reinterpret_cast<float4*>(pb + HW) = make_float4(fby[0], fby[1], fby[2], fby[3]);
+      if (mask_fwd) {
+        *reinterpret_cast<uchar4*>(mask_fwd + (size_t)n * HW + r) = make_uchar4(mf[0], mf[1], mf[2], mf[3]);
+        *reinterpret_cast<uchar4*>(mask_bwd + (size_t)n * HW + r) = make_uchar4(mb[0], mb[1], mb[2], mb[3]);
+      }
+    } else {
+      for (int i = 0; i < PPX && xb + i < g.Wf; ++i) {
+        pf[i] = ffx[i]; pf[HW + i] = ffy[i]; pb[i] = fbx[i]; pb[HW + i] = fby[i];
+        if (mask_fwd) { mask_fwd[(size_t)n * HW + r + i] = mf[i]; mask_bwd[(size_t)n * HW + r + i] = mb[i]; }
+      }
+    }
+  }
+  if (invalid) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { badf += __shfl_xor(badf, o, 64); badb += __shfl_xor(badb, o, 64); }
+    if (threadIdx.x == 0) {
+      if (badf) atomicAdd(&invalid[n], badf);
+      if (badb) atomicAdd(&invalid[N + n], badb);
+    }
+  }
+}
+
 // ---- K8: calc_mask_ratio -----------------------------------------------------------------
 __global__ void k_mask_ratio(const uint8_t* __restrict__ mask, float* __restrict__ ratio, int64_t pixels) {
   __shared__ int red[TPB / WAVE];
@@ -286,7 +467,18 @@ int run_flow_prepare(const float* lo_fwd, const float* lo_bwd, float* flow_fwd, 
     }
   }
   if (F1 == 1) {
-    if (flow_up) {
+    if (flow_up && N <= 65535 && (Hf + PT_Y - 1) / PT_Y <= 65535) {
+      Up8Geom g;
+      g.h = h; g.w = w; g.Hf = Hf; g.Wf = Wf;
+      g.sy = h > 1 ? (float)(h - 1) / (float)(Hf - 1) : 0.f;
+      g.sx = w > 1 ? (float)(w - 1) / (float)(Wf - 1) : 0.f;
+      g.wd = make_divc((float)(Wf - 1)); g.ht = make_divc((float)(Hf - 1));
+      g.hx = (float)(Wf - 1) / 2.f; g.hy = (float)(Hf - 1) / 2.f;
+      g.alpha1 = alpha1; g.a2 = a2;
+      dim3 grid((Wf + PT_X * PPX - 1) / (PT_X * PPX), (Hf + PT_Y - 1) / PT_Y, N);
+      hipLaunchKernelGGL(k_prepare_up8, grid, dim3(PT_X, PT_Y), 0, st, lo_fwd, lo_bwd, flow_fwd, flow_bwd, mask_fwd,
+                         mask_bwd, invalid, N, g);
+    } else if (flow_up) {
       Up8Source sf{lo_fwd, F1, h, w}, sb{lo_bwd, F1, h, w};
       hipLaunchKernelGGL(k_prepare_single<Up8Source>, dim3(blocks_for(n)), dim3(TPB), 0, st, sf, sb, flow_fwd,
                          flow_bwd, mask_fwd, mask_bwd, invalid, N, Hf, Wf, alpha1, a2);

@@ -65,8 +65,9 @@ def test_apply_optical_flow_golden(dev, tag):
     assert torch.allclose(r1, r2, atol=1e-6, rtol=0)
 
 
-@pytest.mark.parametrize("nfr,hw", [(2, (90, 160)), (6, (45, 80)), (3, (23, 37))])
-def test_apply_optical_flow_vs_oracle_full_size(dev, nfr, hw):
+@pytest.mark.parametrize("nfr,hw,sigma", [(2, (90, 160), 0.5), (6, (45, 80), 0.5), (3, (23, 37), 0.5),
+                                          (2, (45, 80), 12.0), (2, (17, 29), 3.0), (2, (2, 2), 0.3)])
+def test_apply_optical_flow_vs_oracle_full_size(dev, nfr, hw, sigma):
     """BDD-sized (720x1280 for nframe 2) and ragged sizes against the oracle; flows bit-exact,
     masks exact."""
     from contrast import util
@@ -74,14 +75,15 @@ def test_apply_optical_flow_vs_oracle_full_size(dev, nfr, hw):
     from recipes import smooth_flow
     gen = torch.Generator().manual_seed(5 + nfr)
     N = 2
-    fw = smooth_flow((N, nfr - 1, 2, *hw), 0.5, gen)
-    bw = -fw.flip(1) + smooth_flow((N, nfr - 1, 2, *hw), 0.05, gen)
+    # sigma 12 low-res px = ~100 full-res px displacements: taps leave the kernel's LDS window (global path)
+    fw = smooth_flow((N, nfr - 1, 2, *hw), sigma, gen)
+    bw = -fw.flip(1) + smooth_flow((N, nfr - 1, 2, *hw), 0.1 * sigma, gen)
     size = torch.tensor([8 * hw[0], 8 * hw[1]])
     (f, _, mf), (b, _, mb) = util.apply_optical_flow(_data(fw, bw, size, nfr, dev), None, _args(True))
     (fo, _, mfo), (bo, _, mbo) = O.apply_optical_flow_file(fw, bw, size, True, 0.01, 0.5)
     assert torch.equal(f.cpu(), fo) and torch.equal(b.cpu(), bo)
     assert torch.equal(mf.cpu(), mfo) and torch.equal(mb.cpu(), mbo)
-    assert 0 < mfo.float().mean() < 1
+    assert 0 < mfo.float().mean() < 1 or hw == (2, 2)
 
 
 def test_apply_optical_flow_variants(dev):
