@@ -1,0 +1,141 @@
+"""Host-side logic that needs no GPU: flags, argument polymorphism, schedules, synthetic records,
+state-dict compatibility, and the 'fail loudly on CPU' contract."""
+import json
+import math
+import os
+import random
+import types
+
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+
+def test_flags_match_reference_recipe():
+    from contrast import option
+    # tools/pretrain_bdd100k_job_base.sh:251-281 flag set (values of the nframe-6 recipe)
+    argv = ["--data-dir", "/d", "--output-dir", "/o", "--dataset", "bdd100k", "--aug", "BYOL", "--crop", "0.08",
+            "--image-size", "224", "224", "--n-frames", "6", "--use_flow", "--use_flow_file", "--flow_up",
+            "--alpha1", "0.01", "--alpha2", "0.5", "--flow_root", "/f", "--fwd_name", "a", "--bwd_name", "b",
+            "--batch-size", "64", "--arch", "resnet50", "--model", "PixPro", "--head-type", "early_return",
+            "--optimizer", "lars", "--base-lr", "1.0", "--weight-decay", "1e-5", "--warmup-epoch", "5",
+            "--epochs", "2000", "--amp-opt-level", "O0", "--save-freq", "10", "--auto-resume", "--zip",
+            "--cache-mode", "no", "--num-workers", "8", "--local_rank", "3",
+            "--pixpro-p", "2", "--pixpro-momentum", "0.99", "--pixpro-pos-ratio", "0.7", "--pixpro-clamp-value", "0.",
+            "--pixpro-transform-layer", "1", "--pixpro-ins-loss-weight", "0."]
+    a = option.parse_option(argv=argv)
+    assert a.image_size == 224 and a.local_rank == 3 and a.debug_epochs == 2001
+    assert a.base_learning_rate == 1.0 and a.pixpro_p == 2.0 and a.use_flow and a.flow_up
+    with pytest.raises(SystemExit):
+        option.parse_option(argv=[])          # --model is required, as in the reference
+
+
+def test_unpack_polymorphism():
+    from contrast.models.PixPro import _unpack
+    cq, ck = torch.rand(2, 10), torch.rand(2, 10)
+    flow, mask = torch.zeros(2, 2, 4, 4), torch.ones(2, 4, 4, dtype=torch.bool)
+    assert _unpack(cq, ck)[2:] == (None, None, None)
+    out = _unpack([cq, flow], [ck, flow])
+    assert out[2] is flow and out[3] is None and out[4] is None
+    out = _unpack([cq, [flow, (4, 4), mask]], [ck, [flow, (4, 4), None]])
+    assert out[0] is cq and out[1] is ck and out[3] == (4, 4) and out[4] is mask
+    out = _unpack([cq, [flow, torch.tensor([4, 4]), [mask, None]]], [ck, [flow, None, None]])
+    assert out[4] is mask
+    with pytest.raises(NotImplementedError):
+        _unpack((cq, None), (ck, None))
+
+
+def test_cpu_tensors_are_rejected_not_emulated():
+    from contrast import util
+    from contrast.models.PixPro import add_optical_flow, regression_loss
+    q = torch.randn(2, 8, 2, 2)
+    c = torch.rand(2, 10)
+    for fn in (lambda: regression_loss(q, q, c, c, 0.7),
+               lambda: util.concat_flow(torch.zeros(2, 1, 2, 4, 4)),
+               lambda: util.upflow8(torch.zeros(1, 2, 4, 4)),
+               lambda: util.forward_backward_consistency(torch.zeros(1, 2, 4, 4), torch.zeros(1, 2, 4, 4)),
+               lambda: add_optical_flow(torch.zeros(2, 2, 4, 4), torch.zeros(2, 2, 2), torch.zeros(2, 2, 2), (4, 4))):
+        with pytest.raises(RuntimeError, match="GPU only|CUDA"):
+            fn()
+
+
+def test_lr_schedule_matches_reference_formula():
+    from contrast.lr_scheduler import get_scheduler
+    args = types.SimpleNamespace(lr_scheduler="cosine", epochs=10, warmup_epoch=2, warmup_multiplier=100,
+                                 lr_decay_epochs=[4, 8], lr_decay_rate=0.1)
+    n_iter = 5
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.SGD([p], lr=4.0)
+    sched = get_scheduler(opt, n_iter, args)
+    got = []
+    for _ in range(50):
+        opt.step(); sched.step(); got.append(opt.param_groups[0]["lr"])
+    warm = 2 * n_iter
+    for step, lr in enumerate(got, start=1):
+        if step <= warm:   # GradualWarmupScheduler.get_lr, contrast/lr_scheduler.py:25-30
+            want = 4.0 / 100 * ((100 - 1.) * step / warm + 1.)
+        else:              # CosineAnnealingLR closed form with eta_min 1e-6, T_max (epochs-warmup)*n_iter
+            t = step - warm
+            want = 1e-6 + (4.0 - 1e-6) * (1 + math.cos(math.pi * t / ((10 - 2) * n_iter))) / 2
+        assert abs(lr - want) < 1e-9, (step, lr, want)
+    args.lr_scheduler = "step"
+    opt = torch.optim.SGD([p], lr=4.0)
+    sched = get_scheduler(opt, n_iter, args)
+    lrs = []
+    for _ in range(45):
+        opt.step(); sched.step(); lrs.append(opt.param_groups[0]["lr"])
+    assert abs(lrs[warm + (4 - 2) * n_iter - 2] - 4.0) < 1e-9 and abs(lrs[warm + (4 - 2) * n_iter - 1] - 0.4) < 1e-9
+    assert abs(lrs[-1] - 0.04) < 1e-9
+
+
+def test_synthetic_batch_layout():
+    from contrast.synthetic import crop_coords, make_batch
+    d = make_batch(3, image_size=16, n_frames=6, frame_hw=(72, 128), device="cpu")
+    im1, im2, c1, c2, idx, (tgt, fw, bw), (size, num) = d
+    assert im1.shape == (3, 3, 16, 16) and c1.shape == (3, 10) and fw.shape == (3, 5, 2, 9, 16)
+    assert torch.equal(bw, -fw.flip(1)) and size.tolist() == [[72, 128]] * 3 and num.tolist() == [[6]] * 3
+    c = crop_coords(200, 1280, 720, random.Random(0))
+    assert torch.all(c[:, 8] == 1280) and torch.all(c[:, 9] == 720)
+    flipped = c[:, 0] > c[:, 2]
+    assert 0.3 < flipped.float().mean() < 0.7                           # p=0.5 flips encoded as x0 > x2
+    lo, hi = torch.minimum(c[:, 0], c[:, 2]), torch.maximum(c[:, 0], c[:, 2])
+    assert torch.allclose(lo * 1279, c[:, 4], atol=1e-3) and torch.allclose(hi * 1279, c[:, 4] + c[:, 6] - 1, atol=1e-3)
+    area = c[:, 6] * c[:, 7] / (1280 * 720)
+    assert area.min() >= 0.07 and area.max() <= 1.0
+
+
+def test_calc_frame_ratio_contract():
+    from contrast.util import calc_frame_ratio
+    mean_f, no_r, per = calc_frame_ratio(torch.tensor([[2], [2], [1], [6]]))
+    assert mean_f == pytest.approx(2.75) and no_r == pytest.approx(0.25)
+    assert per.shape == (6, 2) and per[1].tolist() == [0.5, 2.0] and per[5].tolist() == [0.25, 1.0]
+
+
+def test_state_dict_names_match_reference():
+    from contrast import resnet
+    from contrast.models import PixPro
+    with open(os.path.join(GOLDEN, "model_cfg1_shapes.json")) as fh:
+        ref = {k: tuple(v) for k, v in json.load(fh).items()}
+    args = types.SimpleNamespace(pixpro_p=2.0, pixpro_momentum=0.99, pixpro_pos_ratio=0.7, pixpro_clamp_value=0.0,
+                                 pixpro_transform_layer=1, pixpro_ins_loss_weight=0.0, output_dir="/tmp",
+                                 num_instances=800, batch_size=8, epochs=10, start_epoch=1, feature_dim=256,
+                                 head_type="early_return", sync_bn=False)
+    m = PixPro(resnet.resnet18, args)
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == ref
+    assert m.K == 1000 and m.k == 0
+    assert all(not p.requires_grad for p in m.encoder_k.parameters())
+    # ResNet-50: 656 state tensors, 167 trainable tensors, 33,023,552 trainable elements
+    m50 = PixPro(resnet.resnet50, args)
+    assert len(m50.state_dict()) == 656
+    tr = [p for p in m50.parameters() if p.requires_grad]
+    assert len(tr) == 167 and sum(p.numel() for p in tr) == 33023552
+    assert m50.momentum_coefficient() == pytest.approx(0.99)
+
+
+def test_lars_grouping():
+    from contrast.lars import add_weight_decay
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 1), torch.nn.BatchNorm2d(4))
+    g = add_weight_decay(net, 1e-5)
+    assert [len(x["params"]) for x in g] == [3, 1] and g[0]["ignore"] and not g[1]["ignore"]
+    assert g[0]["weight_decay"] == 0 and g[1]["weight_decay"] == 1e-5
