@@ -221,3 +221,10 @@ int pixpro_lars_sgd_step(float* const* p_ptrs, const float* const* g_ptrs, float
 }
 
 }  // extern "C"
+
+#ifdef PIXPRO_STAMPS
+namespace pixpro { extern __device__ unsigned long long g_stamps[64]; }
+extern "C" int pixpro_debug_stamps(unsigned long long* host64) {
+  return hipMemcpyFromSymbol(host64, HIP_SYMBOL(pixpro::g_stamps), 64 * sizeof(unsigned long long)) == hipSuccess ? 0 : 3;
+}
+#endif

@@ -1,31 +1,42 @@
 // Single-launch PPM -> flow-matched pixel loss -> backward for grids with P = H*W <= 64
 // (7x7 at 224^2 crops, 2x2 at 64^2) and C in {128, 256}.
 //
-// One 512-thread work-group (8 wave64) per (loss direction, sample).  The sample's
-// [C][P] fp32 tiles are contiguous in HBM (NCHW), so each is one linear, fully coalesced
-// 16 B/lane stream into LDS.  All six P x P / C x P contractions run on the exact-fp32 MFMA
-// v_mfma_f32_16x16x4_f32 with both operands read from LDS; S/A/dS never leave the CU.
-// Row reductions over C (three L2 norms and the two projection dot products) are done on
-// the accumulator registers with wave shuffles + one LDS hop across the 8 waves.
+// One 512-thread work-group (8 wave64) per (loss direction, sample).  The sample's [C][P] fp32
+// tiles are contiguous in HBM (NCHW): each is one linear, fully coalesced 16 B/lane stream.
+// All six P x P / C x P contractions run on the exact-fp32 MFMA v_mfma_f32_16x16x4_f32 with both
+// operands read from LDS; S/A/dS never leave the CU.  The tiles stay RAW in LDS: the three L2
+// normalisations over C are applied as per-column reciprocal scales on the MFMA operands / in the
+// epilogues (n_x^2 is the diagonal of the raw Gram matrix), and the two projection dot products
+// are reduced on the accumulator registers (wave shuffles + one LDS hop across the 8 waves).
+// HBM latency is hidden inside the single resident work-group by register prefetch: k streams in
+// under the S contraction, the second read of x under the dA/dV contractions.
 //
-// Phases (reference contrast/models/PixPro.py:339-363,380,92-247):
-//   pts   q/k bin centres, flow displacement (bilinear) + validity (nearest), bit-mask M
-//   S     B0 <- x_hat ; S = x_hat^T x_hat ; A = pow(clamp(S)), D = dA/dS          (P x P, K=C)
-//   Y     B1 <- v_hat ; Y = v_hat A ; n_y ; Y_hat                                  (C x P, K=P)
-//   G     B0 <- k_hat ; G = k_hat M^T ; t_i = <Y_hat_i, G_i> ; loss_n             (C x P, K=P)
-//   dY    B0 <- dY = (gs G - Y_hat gs t)/n_y
-//   dA    dS = (dY^T v_hat) o D ; dSs = dS + dS^T                                 (P x P, K=C)
-//   dV    dv = proj(dY A, v_hat)/n_v  -> HBM                                      (C x P, K=P)
-//   dX    B1 <- x_hat ; dx = proj(x_hat dSs, x_hat)/n_x -> HBM                    (C x P, K=P)
+// Buffers over time (B0, B1 = two [C][P] LDS tiles):
+//   B0: x (S)  -> k (G) -> dY (dA, dV) -> x (dX, dx out)         B1: v (Y, dA, dV epilogue, dv out)
+//
+// Math: SURVEY.md Appendix A; reference contrast/models/PixPro.py:339-363,380,403 (PPM + the three
+// F.normalize), :92-247 (regression_loss), :46-89 (add_optical_flow).
 #include "common.h"
 
 namespace pixpro {
+
+#ifdef PIXPRO_STAMPS   // diagnostic build only (tools/ppm_phase_stamps.py): wave 0 of block 0 stamps s_memtime
+__device__ unsigned long long g_stamps[64];
+#define STAMP(i)                                                                            \
+  do {                                                                                      \
+    if (blockIdx.x == 0 && threadIdx.x == 0) g_stamps[i] = __builtin_amdgcn_s_memtime();    \
+  } while (0)
+#else
+#define STAMP(i)
+#endif
 
 namespace {
 
 constexpr int NTHREADS = 512;
 constexpr int NWAVES = NTHREADS / WAVE;
-constexpr int LS = 80;  // row stride of the small P x P matrices (80 % 32 == 16: conflict-free row pairs)
+constexpr int LS = 80;    // row stride of the small P x P matrices (80 % 32 == 16: conflict-free row pairs)
+constexpr int PF = 7;     // float4 prefetch registers per thread: 7 * 512 * 4 >= 256 * 49
+constexpr int KU = 8;     // k-unroll of the K = C contractions (operand loads issued KU steps ahead)
 
 struct Smem {
   float* B0;     // [C*P + 4]
@@ -33,17 +44,19 @@ struct Smem {
   float* AA;     // [LR][LS]   A = pow(clamp(S))
   float* Dm;     // [LR][LS]   dA/dS, later dS + dS^T
   float* DS;     // [LR][LS]   dS
-  float* nx;     // [64]
-  float* nv;
-  float* ny;
-  float* tcol;
-  float* scol;
+  float* rx;     // [64] reciprocal column norms of x, v, k, Y
+  float* rv;
+  float* rk;
+  float* ry;
+  float* nx2;    // [64] diag of the raw Gram matrix
+  float* tcol;   // [64]
+  float* scol;   // [64]
   float* part;   // [NWAVES][64]
   float* qx;     // [64] each
   float* qy;
   float* kx;
   float* ky;
-  float* misc;   // [8]: diag, cnt, ...
+  float* misc;   // [16]: diag, cnt, -, ..., [8 + w] = per-wave positive counts
   unsigned long long* mbits;  // [64]
   int* valid;    // [64]
 };
@@ -51,7 +64,7 @@ struct Smem {
 __host__ __device__ inline int lr_rows(int P) { return (P + 3) / 4 * 4; }
 
 __host__ __device__ inline size_t smem_floats(int C, int P) {
-  return 2 * ((size_t)C * P + 4) + 3 * (size_t)lr_rows(P) * LS + 5 * 64 + NWAVES * 64 + 4 * 64 + 8 + 2 * 64 + 64;
+  return 2 * ((size_t)C * P + 4) + 3 * (size_t)lr_rows(P) * LS + 7 * 64 + NWAVES * 64 + 4 * 64 + 16 + 2 * 64 + 64;
 }
 
 __device__ __forceinline__ Smem carve(float* base, int C, int P) {
@@ -63,54 +76,64 @@ __device__ __forceinline__ Smem carve(float* base, int C, int P) {
   s.AA = p; p += LR * LS;
   s.Dm = p; p += LR * LS;
   s.DS = p; p += LR * LS;
-  s.nx = p; p += 64; s.nv = p; p += 64; s.ny = p; p += 64; s.tcol = p; p += 64; s.scol = p; p += 64;
+  s.rx = p; p += 64; s.rv = p; p += 64; s.rk = p; p += 64; s.ry = p; p += 64;
+  s.nx2 = p; p += 64; s.tcol = p; p += 64; s.scol = p; p += 64;
   s.part = p; p += NWAVES * 64;
   s.qx = p; p += 64; s.qy = p; p += 64; s.kx = p; p += 64; s.ky = p; p += 64;
-  s.misc = p; p += 8;
+  s.misc = p; p += 16;
   s.mbits = (unsigned long long*)p; p += 2 * 64;
   s.valid = (int*)p;
   return s;
 }
 
-// linear HBM -> LDS copy of one [C][P] tile (count % 4 == 0, both 16-B aligned)
-__device__ __forceinline__ void load_tile(float* __restrict__ dst, const float* __restrict__ src, int count) {
-  for (int e = threadIdx.x * 4; e < count; e += NTHREADS * 4)
-    *reinterpret_cast<float4*>(dst + e) = *reinterpret_cast<const float4*>(src + e);
+// HBM -> registers (issue only) and registers -> LDS of one [C][P] tile (count % 4 == 0, 16-B aligned)
+struct Prefetch {
+  float4 r[PF];
+};
+__device__ __forceinline__ void pf_issue(Prefetch& p, const float* __restrict__ src, int count) {
+#pragma unroll
+  for (int i = 0; i < PF; ++i) {
+    const int e = (threadIdx.x + i * NTHREADS) * 4;
+    if (e < count) p.r[i] = *reinterpret_cast<const float4*>(src + e);
+  }
+}
+__device__ __forceinline__ void pf_commit(const Prefetch& p, float* __restrict__ dst, int count) {
+#pragma unroll
+  for (int i = 0; i < PF; ++i) {
+    const int e = (threadIdx.x + i * NTHREADS) * 4;
+    if (e < count) *reinterpret_cast<float4*>(dst + e) = p.r[i];
+  }
 }
 __device__ __forceinline__ void store_tile(float* __restrict__ dst, const float* __restrict__ src, int count) {
   for (int e = threadIdx.x * 4; e < count; e += NTHREADS * 4)
     *reinterpret_cast<float4*>(dst + e) = *reinterpret_cast<const float4*>(src + e);
 }
 
-// norms[j] = max(||buf[:,j]||, 1e-12) for j < P  (ends with a barrier)
-__device__ __forceinline__ void col_norms(const float* buf, float* norms, float* part, int C, int P) {
+// rn[j] = 1 / max(||buf[:,j]||, 1e-12) for j < P  (ends with a barrier)
+__device__ __forceinline__ void col_rnorms(const float* buf, float* rn, float* part, int C, int P) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int rows = C / NWAVES;
-  float acc = 0.f;
-  if (lane < P)
-    for (int c = wave * rows; c < (wave + 1) * rows; ++c) { float t = buf[c * P + lane]; acc += t * t; }
-  part[wave * 64 + lane] = acc;
+  float a0 = 0.f, a1 = 0.f;
+  if (lane < P) {
+    const float* p = buf + wave * rows * P + lane;
+    for (int c = 0; c < rows; c += 2) {
+      const float t0 = p[c * P], t1 = p[(c + 1) * P];
+      a0 = __builtin_fmaf(t0, t0, a0);
+      a1 = __builtin_fmaf(t1, t1, a1);
+    }
+  }
+  part[wave * 64 + lane] = a0 + a1;
   __syncthreads();
   if (threadIdx.x < 64) {
     float t = 0.f;
 #pragma unroll
     for (int w = 0; w < NWAVES; ++w) t += part[w * 64 + threadIdx.x];
-    norms[threadIdx.x] = fmaxf(sqrtf(t), 1e-12f);
+    rn[threadIdx.x] = 1.f / fmaxf(sqrtf(t), 1e-12f);
   }
   __syncthreads();
 }
 
-// buf[c][j] /= norms[j]   (no barrier)
-__device__ __forceinline__ void scale_cols(float* buf, const float* norms, int C, int P) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (lane < P) {
-    const float n = norms[lane];
-    for (int c = wave; c < C; c += NWAVES) buf[c * P + lane] = buf[c * P + lane] / n;
-  }
-}
-
-// Cross-wave column reduction of per-lane partials v[n] (column 16n + (lane&15)).
-// out[col] = sum over all rows; ends with a barrier.
+// Cross-wave column reduction of per-lane partials v[n] (column 16n + (lane&15)); ends with a barrier.
 template <int NT>
 __device__ __forceinline__ void col_reduce(float (&v)[NT], float* out, float* part) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -131,9 +154,10 @@ __device__ __forceinline__ void col_reduce(float (&v)[NT], float* out, float* pa
   __syncthreads();
 }
 
-// acc[m][n] += sum_k Aop(row tile m, k) * Bop(k, col tile n) over `ksteps` steps of 4.
+// C x P contraction: acc[m][n] += sum_k Aop(m, k) * Bop(n, k), k in steps of 4 (8 MFMAs per step hide
+// the LDS latency of the next step's operands).
 template <int MT, int NT, class FA, class FB>
-__device__ __forceinline__ void gemm(f32x4 (&acc)[MT][NT], int ksteps, FA fa, FB fb) {
+__device__ __forceinline__ void gemm_cp(f32x4 (&acc)[MT][NT], int ksteps, FA fa, FB fb) {
   for (int ks = 0; ks < ksteps; ++ks) {
     float a[MT], b[NT];
 #pragma unroll
@@ -144,6 +168,38 @@ __device__ __forceinline__ void gemm(f32x4 (&acc)[MT][NT], int ksteps, FA fa, FB
     for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int n = 0; n < NT; ++n) acc[m][n] = mfma16(a[m], b[n], acc[m][n]);
+  }
+}
+
+// P x P contraction over K = C for up to two output tiles per wave (tiles `wave` and `wave + 8` of the
+// NT x NT grid): out[i][j] = sum_c L[c][i] * R[c][j].  Operand loads are issued KU k-steps ahead.
+template <int NT>
+__device__ __forceinline__ void gemm_pp(f32x4& acc0, f32x4& acc1, const float* __restrict__ L,
+                                        const float* __restrict__ R, int C, int P) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
+  const int t0 = wave, t1 = wave + NWAVES;
+  const bool has0 = t0 < NT * NT, has1 = t1 < NT * NT;
+  if (!has0) return;
+  const int i0 = min(16 * (t0 / NT) + lr, P - 1), j0 = min(16 * (t0 % NT) + lr, P - 1);
+  const int i1 = has1 ? min(16 * (t1 / NT) + lr, P - 1) : i0, j1 = has1 ? min(16 * (t1 % NT) + lr, P - 1) : j0;
+  const float* la = L + lq * P + i0;
+  const float* rb = R + lq * P + j0;
+  const float* lc = L + lq * P + i1;
+  const float* rd = R + lq * P + j1;
+  const int step = 4 * P;
+  for (int k0 = 0; k0 < C / 4; k0 += KU) {
+    float a[KU], b[KU], c[KU], d[KU];
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+      a[u] = la[u * step]; b[u] = rb[u * step];
+      if (has1) { c[u] = lc[u * step]; d[u] = rd[u * step]; }
+    }
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+      acc0 = mfma16(a[u], b[u], acc0);
+      if (has1) acc1 = mfma16(c[u], d[u], acc1);
+    }
+    la += KU * step; rb += KU * step; lc += KU * step; rd += KU * step;
   }
 }
 
@@ -158,16 +214,22 @@ ppm_fused_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* _
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
   const int b = blockIdx.x, dir = b / N, n = b % N;
   const pixpro_dir& dd = D.d[dir];
-  const size_t tile = (size_t)C * P;
+  const int tile = C * P;
   const float* gx = dd.x + (size_t)n * tile;
   const float* gv = dd.v + (size_t)n * tile;
   const float* gk = dd.k + (size_t)n * tile;
   const int KS = LR / 4;          // k-steps over the pixel dimension
-  const int KC = C / 4;           // k-steps over the channel dimension
   const bool want_grad = dd.dx != nullptr;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  // row of the wave's m-th C-tile owned by this lane as A operand / as accumulator register r
+  auto arow = [&](int m) { return 16 * (wave + NWAVES * m) + lr; };
+  auto crow = [&](int m, int r) { return 16 * (wave + NWAVES * m) + 4 * lq + r; };
 
-  // ---- stage x ; bin centres, flow displacement, validity (independent of the loads) ----
-  load_tile(sm.B0, gx, (int)tile);
+  STAMP(0);
+  // ---- x -> B0 and v -> B1 in flight together; bin centres / flow taps meanwhile ----
+  Prefetch pfa, pfb;
+  pf_issue(pfa, gx, tile);
+  pf_issue(pfb, gv, tile);
   if (tid < 4) { sm.B0[tile + tid] = 0.f; sm.B1[tile + tid] = 0.f; }
   if (tid < 64) {
     float qx = 0.f, qy = 0.f, kx = 0.f, ky = 0.f;
@@ -194,7 +256,11 @@ ppm_fused_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* _
     }
     sm.qx[tid] = qx; sm.qy[tid] = qy; sm.kx[tid] = kx; sm.ky[tid] = ky; sm.valid[tid] = valid;
   }
+  pf_commit(pfa, sm.B0, tile);
+  pf_commit(pfb, sm.B1, tile);
+  pf_issue(pfa, gk, tile);          // k streams in under the mask / norm / S phases
   __syncthreads();
+  STAMP(1);
 
   // ---- positive-pair bit mask: row i of M = ballot over j (PixPro.py:217-223) ----
   {
@@ -212,57 +278,72 @@ ppm_fused_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* _
       if (lane == 0) sm.mbits[i] = bits;
       cnt_w += __popcll(bits);
     }
-    if (lane == 0) sm.part[wave * 64] = (float)cnt_w;
+    if (lane == 0) sm.misc[8 + wave] = (float)cnt_w;
   }
   __syncthreads();
   if (tid == 0) {
     float c = 0.f;
-    for (int w = 0; w < NWAVES; ++w) c += sm.part[w * 64];
+    for (int w = 0; w < NWAVES; ++w) c += sm.misc[8 + w];
     sm.misc[1] = c;
   }
-  // ---- x_hat in B0 ----
-  col_norms(sm.B0, sm.nx, sm.part, C, P);
-  scale_cols(sm.B0, sm.nx, C, P);
-  // prefetch of v into B1 overlaps the S phase
-  load_tile(sm.B1, gv, (int)tile);
-  __syncthreads();
+  STAMP(2);
+  col_rnorms(sm.B1, sm.rv, sm.part, C, P);            // (barriers inside also publish misc[1])
+  STAMP(3);
 
-  // ---- S = x_hat^T x_hat ; A, D ----
-  for (int t0 = wave; t0 < NT * NT; t0 += NWAVES) {
-    const int mi = t0 / NT, nj = t0 % NT;
-    const int ca = min(16 * mi + lr, P - 1), cb = min(16 * nj + lr, P - 1);
-    f32x4 acc[1][1] = {{{0.f, 0.f, 0.f, 0.f}}};
-    gemm<1, 1>(acc, KC,
-               [&](int, int ks) { return sm.B0[(4 * ks + lq) * P + ca]; },
-               [&](int, int ks) { return sm.B0[(4 * ks + lq) * P + cb]; });
+  // ---- S_raw = x^T x ; rx from its diagonal ; S, A, D ----
+  {
+    f32x4 acc0 = zero4, acc1 = zero4;
+    gemm_pp<NT>(acc0, acc1, sm.B0, sm.B0, C, P);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int i = 16 * mi + 4 * lq + r, j = 16 * nj + lr;
-      if (i < LR) {
-        float a = 0.f, d = 0.f;
-        if (i < P && j < P) pow_map(acc[0][0][r], pb.p, pb.clamp, a, d);
-        sm.AA[i * LS + j] = a;
-        sm.Dm[i * LS + j] = d;
+    for (int t = 0; t < 2; ++t) {
+      const int tt = wave + NWAVES * t;
+      if (tt < NT * NT && tt / NT == tt % NT) {
+        const f32x4& acc = t ? acc1 : acc0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (4 * lq + r == lr) sm.nx2[16 * (tt / NT) + lr] = acc[r];
+      }
+    }
+    __syncthreads();
+    if (tid < 64) sm.rx[tid] = 1.f / fmaxf(sqrtf(sm.nx2[tid < 16 * NT ? tid : 0]), 1e-12f);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int tt = wave + NWAVES * t;
+      if (tt < NT * NT) {
+        const f32x4& acc = t ? acc1 : acc0;
+        const int mi = tt / NT, nj = tt % NT, j = 16 * nj + lr;
+        const float rxj = sm.rx[j];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = 16 * mi + 4 * lq + r;
+          if (i < LR) {
+            float a = 0.f, d = 0.f;
+            if (i < P && j < P) pow_map(acc[r] * sm.rx[i] * rxj, pb.p, pb.clamp, a, d);
+            sm.AA[i * LS + j] = a;
+            sm.Dm[i * LS + j] = d;
+          }
+        }
       }
     }
   }
-  __syncthreads();
-  // ---- v_hat in B1 ----
-  col_norms(sm.B1, sm.nv, sm.part, C, P);
-  scale_cols(sm.B1, sm.nv, C, P);
-  __syncthreads();
+  __syncthreads();                 // every wave is done with x in B0
+  pf_commit(pfa, sm.B0, tile);     // k -> B0
+  STAMP(4);
 
   // ---- Y = v_hat A ----
   f32x4 Y[MT][NT];
 #pragma unroll
   for (int m = 0; m < MT; ++m)
 #pragma unroll
-    for (int nn = 0; nn < NT; ++nn) Y[m][nn] = f32x4{0.f, 0.f, 0.f, 0.f};
-  gemm<MT, NT>(Y, KS,
-               [&](int m, int ks) { return sm.B1[(16 * (wave + NWAVES * m) + lr) * P + min(4 * ks + lq, P - 1)]; },
-               [&](int nn, int ks) { return sm.AA[(4 * ks + lq) * LS + 16 * nn + lr]; });
-  // k tile can stream into B0 now (x_hat no longer needed until the dX phase)
-  load_tile(sm.B0, gk, (int)tile);
+    for (int nn = 0; nn < NT; ++nn) Y[m][nn] = zero4;
+  gemm_cp<MT, NT>(Y, KS,
+                  [&](int m, int ks) {
+                    const int j = min(4 * ks + lq, P - 1);
+                    return sm.B1[arow(m) * P + j] * sm.rv[j];
+                  },
+                  [&](int nn, int ks) { return sm.AA[(4 * ks + lq) * LS + 16 * nn + lr]; });
+  STAMP(5);
   {
     float v[NT];
 #pragma unroll
@@ -271,24 +352,25 @@ ppm_fused_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* _
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s += Y[m][nn][r] * Y[m][nn][r];
+        for (int r = 0; r < 4; ++r) s = __builtin_fmaf(Y[m][nn][r], Y[m][nn][r], s);
       v[nn] = s;
     }
-    col_reduce<NT>(v, sm.tcol, sm.part);   // also publishes the k tile (barriers inside)
+    col_reduce<NT>(v, sm.tcol, sm.part);   // barriers inside also publish k in B0
   }
-  if (tid < 64) sm.ny[tid] = fmaxf(sqrtf(sm.tcol[tid < 16 * NT ? tid : 0]), 1e-12f);
+  if (tid < 64) sm.ry[tid] = 1.f / fmaxf(sqrtf(sm.tcol[tid < 16 * NT ? tid : 0]), 1e-12f);
   if (pb.normalize_k) {
-    col_norms(sm.B0, sm.scol, sm.part, C, P);
-    scale_cols(sm.B0, sm.scol, C, P);
+    col_rnorms(sm.B0, sm.rk, sm.part, C, P);
+  } else {
+    if (tid < 64) sm.rk[tid] = 1.f;
+    __syncthreads();
   }
-  __syncthreads();
 #pragma unroll
   for (int nn = 0; nn < NT; ++nn) {
-    const float nyv = sm.ny[16 * nn + lr];
+    const float ryv = sm.ry[16 * nn + lr];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) Y[m][nn][r] = Y[m][nn][r] / nyv;
+      for (int r = 0; r < 4; ++r) Y[m][nn][r] = Y[m][nn][r] * ryv;
   }
   if (dd.pred) {
     float* gp = dd.pred + (size_t)n * tile;
@@ -298,25 +380,30 @@ ppm_fused_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* _
       for (int nn = 0; nn < NT; ++nn)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int c = 16 * (wave + NWAVES * m) + 4 * lq + r, i = 16 * nn + lr;
-          if (i < P) gp[(size_t)c * P + i] = Y[m][nn][r];
+          const int i = 16 * nn + lr;
+          if (i < P) gp[(size_t)crow(m, r) * P + i] = Y[m][nn][r];
         }
   }
+  STAMP(6);
 
   // ---- G = k_hat M^T ----
   f32x4 G[MT][NT];
 #pragma unroll
   for (int m = 0; m < MT; ++m)
 #pragma unroll
-    for (int nn = 0; nn < NT; ++nn) G[m][nn] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int nn = 0; nn < NT; ++nn) G[m][nn] = zero4;
   {
     unsigned long long rowbits[NT];
 #pragma unroll
-    for (int nn = 0; nn < NT; ++nn) rowbits[nn] = sm.mbits[16 * nn + lr];
-    gemm<MT, NT>(G, KS,
-                 [&](int m, int ks) { return sm.B0[(16 * (wave + NWAVES * m) + lr) * P + min(4 * ks + lq, P - 1)]; },
-                 [&](int nn, int ks) { return ((rowbits[nn] >> (4 * ks + lq)) & 1ull) ? 1.f : 0.f; });
+    for (int nn = 0; nn < NT; ++nn) rowbits[nn] = sm.mbits[16 * nn + lr] >> lq;
+    gemm_cp<MT, NT>(G, KS,
+                    [&](int m, int ks) {
+                      const int j = min(4 * ks + lq, P - 1);
+                      return sm.B0[arow(m) * P + j] * sm.rk[j];
+                    },
+                    [&](int nn, int ks) { return ((rowbits[nn] >> (4 * ks)) & 1ull) ? 1.f : 0.f; });
   }
+  STAMP(7);
   {
     float v[NT];
 #pragma unroll
@@ -325,152 +412,164 @@ ppm_fused_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* _
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s += Y[m][nn][r] * G[m][nn][r];
+        for (int r = 0; r < 4; ++r) s = __builtin_fmaf(Y[m][nn][r], G[m][nn][r], s);
       v[nn] = s;
     }
-    col_reduce<NT>(v, sm.tcol, sm.part);   // barrier: every wave is done reading k_hat from B0
+    col_reduce<NT>(v, sm.tcol, sm.part);   // barrier: every wave is done reading k from B0
   }
   const float cnt = sm.misc[1];
   const float den = cnt + 1e-6f;
-  if (tid == 0) {
-    float t = 0.f;
-    for (int i = 0; i < P; ++i) t += sm.tcol[i];
-    loss_n[b] = t / den;
-    pos_num[b] = cnt;
-    pos_mean[b] = cnt / (float)P / (float)P;
+  if (wave == 0) {
+    float t = lane < P ? sm.tcol[lane] : 0.f;
+    t = wave_sum(t);
+    if (lane == 0) {
+      loss_n[b] = t / den;
+      pos_num[b] = cnt;
+      pos_mean[b] = cnt / (float)P / (float)P;
+    }
   }
+  STAMP(8);
   if (!want_grad) return;
 
-  // ---- dY -> B0 ----
+  // ---- dY -> B0 ; second read of x starts ----
+  pf_issue(pfa, gx, tile);
   {
     const float gs = pb.grad_scale * -2.f / (float)N / den;
 #pragma unroll
     for (int nn = 0; nn < NT; ++nn) {
       const int i = 16 * nn + lr;
       if (i < P) {
-        const float ti = gs * sm.tcol[i], nyv = sm.ny[i];
+        const float ti = gs * sm.tcol[i], ryv = sm.ry[i];
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int c = 16 * (wave + NWAVES * m) + 4 * lq + r;
-            sm.B0[c * P + i] = (gs * G[m][nn][r] - Y[m][nn][r] * ti) / nyv;
-          }
+          for (int r = 0; r < 4; ++r) sm.B0[crow(m, r) * P + i] = (gs * G[m][nn][r] - Y[m][nn][r] * ti) * ryv;
       }
     }
   }
   __syncthreads();
+  STAMP(9);
 
   // ---- dA = dY^T v_hat ; dS = dA o D ----
-  for (int t0 = wave; t0 < NT * NT; t0 += NWAVES) {
-    const int mi = t0 / NT, nj = t0 % NT;
-    const int ca = min(16 * mi + lr, P - 1), cb = min(16 * nj + lr, P - 1);
-    f32x4 acc[1][1] = {{{0.f, 0.f, 0.f, 0.f}}};
-    gemm<1, 1>(acc, KC,
-               [&](int, int ks) { return sm.B0[(4 * ks + lq) * P + ca]; },
-               [&](int, int ks) { return sm.B1[(4 * ks + lq) * P + cb]; });
+  {
+    f32x4 acc0 = zero4, acc1 = zero4;
+    gemm_pp<NT>(acc0, acc1, sm.B0, sm.B1, C, P);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int i = 16 * mi + 4 * lq + r, j = 16 * nj + lr;
-      if (i < LR) sm.DS[i * LS + j] = acc[0][0][r] * sm.Dm[i * LS + j];
+    for (int t = 0; t < 2; ++t) {
+      const int tt = wave + NWAVES * t;
+      if (tt < NT * NT) {
+        const f32x4& acc = t ? acc1 : acc0;
+        const int mi = tt / NT, nj = tt % NT, j = 16 * nj + lr;
+        const float rvj = sm.rv[j];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = 16 * mi + 4 * lq + r;
+          if (i < LR) sm.DS[i * LS + j] = acc[r] * rvj * sm.Dm[i * LS + j];
+        }
+      }
     }
   }
   __syncthreads();
-  // dSs = dS + dS^T into Dm (rows/cols >= P are zero because D is zero there)
+  STAMP(10);
+  // dSs = dS + dS^T into Dm (rows/cols >= P are zero because D is zero there); published by the barriers
+  // of the dV epilogue, first read by the dX contraction
   for (int e = tid; e < LR * 64; e += NTHREADS) {
     const int i = e >> 6, j = e & 63;
     sm.Dm[i * LS + j] = (j < LR) ? sm.DS[i * LS + j] + sm.DS[j * LS + i] : 0.f;
   }
-  // (visible after the barriers inside the dV epilogue's col_reduce; the dV gemm below reads AA only)
+  STAMP(11);
 
-  // ---- dV_hat = dY A ; dv = (dV_hat - v_hat s)/n_v ----
+  // ---- dV_hat = dY A ; dv = (dV_hat - v_hat s) / n_v ----
   {
     f32x4 T[MT][NT];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-      for (int nn = 0; nn < NT; ++nn) T[m][nn] = f32x4{0.f, 0.f, 0.f, 0.f};
-    gemm<MT, NT>(T, KS,
-                 [&](int m, int ks) { return sm.B0[(16 * (wave + NWAVES * m) + lr) * P + min(4 * ks + lq, P - 1)]; },
-                 [&](int nn, int ks) { return sm.AA[(4 * ks + lq) * LS + 16 * nn + lr]; });
+      for (int nn = 0; nn < NT; ++nn) T[m][nn] = zero4;
+    gemm_cp<MT, NT>(T, KS,
+                    [&](int m, int ks) { return sm.B0[arow(m) * P + min(4 * ks + lq, P - 1)]; },
+                    [&](int nn, int ks) { return sm.AA[(4 * ks + lq) * LS + 16 * nn + lr]; });
+    float vh[MT][NT][4];
     float v[NT];
 #pragma unroll
     for (int nn = 0; nn < NT; ++nn) {
       const int j = 16 * nn + lr;
       float s = 0.f;
-      if (j < P) {
+      const float rvj = sm.rv[min(j, P - 1)];
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+      for (int m = 0; m < MT; ++m)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) s += sm.B1[(16 * (wave + NWAVES * m) + 4 * lq + r) * P + j] * T[m][nn][r];
-      }
+        for (int r = 0; r < 4; ++r) {
+          vh[m][nn][r] = (j < P) ? sm.B1[crow(m, r) * P + j] * rvj : 0.f;
+          s = __builtin_fmaf(vh[m][nn][r], T[m][nn][r], s);
+        }
       v[nn] = s;
     }
-    col_reduce<NT>(v, sm.scol, sm.part);
+    col_reduce<NT>(v, sm.scol, sm.part);     // barrier: every wave is done reading dY from B0
+    pf_commit(pfa, sm.B0, tile);             // x -> B0 (second read)
 #pragma unroll
     for (int nn = 0; nn < NT; ++nn) {
       const int j = 16 * nn + lr;
       if (j < P) {
-        const float sj = sm.scol[j], nvj = sm.nv[j];
+        const float sj = sm.scol[j], rvj = sm.rv[j];
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int idx = (16 * (wave + NWAVES * m) + 4 * lq + r) * P + j;
-            sm.B1[idx] = (T[m][nn][r] - sm.B1[idx] * sj) / nvj;
-          }
+          for (int r = 0; r < 4; ++r) sm.B1[crow(m, r) * P + j] = (T[m][nn][r] - vh[m][nn][r] * sj) * rvj;
       }
     }
   }
   __syncthreads();
-  store_tile(dd.dv + (size_t)n * tile, sm.B1, (int)tile);
-  __syncthreads();
+  STAMP(12);
+  store_tile(dd.dv + (size_t)n * tile, sm.B1, tile);
+  STAMP(13);
 
-  // ---- x_hat back into B1 ; dX_hat = x_hat dSs ; dx ----
-  load_tile(sm.B1, gx, (int)tile);
-  __syncthreads();
-  scale_cols(sm.B1, sm.nx, C, P);
-  __syncthreads();
+  // ---- dX_hat = x_hat dSs ; dx = (dX_hat - x_hat s) / n_x ----
   {
     f32x4 T[MT][NT];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-      for (int nn = 0; nn < NT; ++nn) T[m][nn] = f32x4{0.f, 0.f, 0.f, 0.f};
-    gemm<MT, NT>(T, KS,
-                 [&](int m, int ks) { return sm.B1[(16 * (wave + NWAVES * m) + lr) * P + min(4 * ks + lq, P - 1)]; },
-                 [&](int nn, int ks) { return sm.Dm[(4 * ks + lq) * LS + 16 * nn + lr]; });
+      for (int nn = 0; nn < NT; ++nn) T[m][nn] = zero4;
+    gemm_cp<MT, NT>(T, KS,
+                    [&](int m, int ks) {
+                      const int j = min(4 * ks + lq, P - 1);
+                      return sm.B0[arow(m) * P + j] * sm.rx[j];
+                    },
+                    [&](int nn, int ks) { return sm.Dm[(4 * ks + lq) * LS + 16 * nn + lr]; });
+    float xh[MT][NT][4];
     float v[NT];
 #pragma unroll
     for (int nn = 0; nn < NT; ++nn) {
       const int j = 16 * nn + lr;
       float s = 0.f;
-      if (j < P) {
+      const float rxj = sm.rx[min(j, P - 1)];
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+      for (int m = 0; m < MT; ++m)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) s += sm.B1[(16 * (wave + NWAVES * m) + 4 * lq + r) * P + j] * T[m][nn][r];
-      }
+        for (int r = 0; r < 4; ++r) {
+          xh[m][nn][r] = (j < P) ? sm.B0[crow(m, r) * P + j] * rxj : 0.f;
+          s = __builtin_fmaf(xh[m][nn][r], T[m][nn][r], s);
+        }
       v[nn] = s;
     }
-    col_reduce<NT>(v, sm.scol, sm.part);
+    col_reduce<NT>(v, sm.scol, sm.part);     // barrier: every wave is done reading x from B0
 #pragma unroll
     for (int nn = 0; nn < NT; ++nn) {
       const int j = 16 * nn + lr;
       if (j < P) {
-        const float sj = sm.scol[j], nxj = sm.nx[j];
+        const float sj = sm.scol[j], rxj = sm.rx[j];
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int idx = (16 * (wave + NWAVES * m) + 4 * lq + r) * P + j;
-            sm.B1[idx] = (T[m][nn][r] - sm.B1[idx] * sj) / nxj;
-          }
+          for (int r = 0; r < 4; ++r) sm.B0[crow(m, r) * P + j] = (T[m][nn][r] - xh[m][nn][r] * sj) * rxj;
       }
     }
   }
   __syncthreads();
-  store_tile(dd.dx + (size_t)n * tile, sm.B1, (int)tile);
+  STAMP(14);
+  store_tile(dd.dx + (size_t)n * tile, sm.B0, tile);
+  STAMP(15);
 }
 
 template <int MT, int NT>
@@ -498,6 +597,7 @@ bool fused_supported(const pixpro_problem& pb) {
   const int P = pb.H * pb.W;
   if (P > 64 || P < 1) return false;
   if (pb.C != 128 && pb.C != 256) return false;
+  if ((size_t)pb.C * P > (size_t)PF * NTHREADS * 4) return false;
   return smem_floats(pb.C, P) * sizeof(float) <= 160 * 1024;
 }
 

@@ -1,0 +1,55 @@
+#!/usr/bin/env python
+"""Diagnostic: per-phase s_memtime stamps of ppm_fused_kernel (block 0, wave 0).  Builds a separate
+library with -DPIXPRO_STAMPS (never the shipped one) and prints the cycle share of each phase."""
+import ctypes
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "pixpro-with-opticalflow_amd")
+sys.path.insert(0, PKG)
+import torch  # noqa: E402
+
+NAMES = ["start", "load x,v + pts", "maskbits", "rv norms", "S gemm+epi", "Y gemm", "ny, rk, Yhat", "G gemm", "loss",
+         "dY", "dA gemm+epi", "symm", "dV gemm+epi", "store dv", "dX gemm+epi", "store dx"]
+
+
+def main():
+    out = "/tmp/libpixpro_hip_stamps.so"
+    srcs = [os.path.join(PKG, "csrc", f) for f in ("capi.hip", "ppm_fused.hip", "ppm_generic.hip", "flow_prep.hip",
+                                                   "multi_tensor.hip")]
+    subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
+                    "-ffp-contract=off", "-DPIXPRO_STAMPS", "-fgpu-rdc", "-o", out] + srcs, check=True)
+    from contrast import _native
+    _native.LIB_PATH = out
+    from contrast import ops
+    dev = torch.device("cuda:0")
+    N, C, G = 256, 256, 7
+    gen = torch.Generator(device=dev).manual_seed(0)
+    t = lambda: torch.randn(N, C, G, G, device=dev, generator=gen)
+    x1, v1, x2, v2, k1, k2 = (t() for _ in range(6))
+    for z in (x1, v1, x2, v2):
+        z.requires_grad_(True)
+    from contrast.synthetic import crop_coords
+    import random
+    c1 = crop_coords(N, 1280, 720, random.Random(0)).to(dev)
+    c2 = crop_coords(N, 1280, 720, random.Random(1)).to(dev)
+    flow = torch.randn(N, 2, 90, 160, device=dev, generator=gen)
+    mask = torch.rand(N, 90, 160, device=dev, generator=gen) > 0.1
+    for _ in range(3):
+        d1 = ops.Direction(x1, v1, k2, c1, c2, flow, mask, (720, 1280))
+        d2 = ops.Direction(x2, v2, k1, c2, c1, flow, mask, (720, 1280))
+        ops.ppm_loss([d1, d2], 2.0, 0.0, 0.7, True)
+    torch.cuda.synchronize()
+    buf = (ctypes.c_ulonglong * 64)()
+    assert _native.load().pixpro_debug_stamps(buf) == 0
+    st = list(buf)[:16]
+    tot = st[15] - st[0]
+    print(f"total ticks {tot} (s_memtime, 100 MHz const clock? -> {tot / 100:.1f} us if so)")
+    for i in range(1, 16):
+        print(f"{NAMES[i]:>16s} {st[i] - st[i - 1]:8d} {100.0 * (st[i] - st[i - 1]) / tot:5.1f}%")
+
+
+if __name__ == "__main__":
+    main()
