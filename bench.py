@@ -42,7 +42,8 @@ def parse():
     ap.add_argument("--arch", default="resnet50")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-flow-images", type=int, default=8)
-    ap.add_argument("--channels-last", action="store_true")
+    ap.add_argument("--no-channels-last", dest="channels_last", action="store_false",
+                    help="keep NCHW activations (default: channels_last, which MIOpen's fp32 implicit-GEMM kernels prefer)")
     return ap.parse_args()
 
 
@@ -67,20 +68,26 @@ def model_args(a, world):
 
 
 class KernelClock:
-    """HIP-event pairs recorded on the launch stream around hot-path calls inside the timed steps."""
+    """HIP-event pairs recorded on the launch stream immediately around the C-ABI calls of the hot path
+    (contrast._native.call), inside the timed steps."""
 
-    def __init__(self):
+    def __init__(self, names):
         self.pairs = {}
+        self.names = names
 
-    def wrap(self, name, fn):
-        def timed(*a, **k):
+    def install(self, native):
+        inner = native.call
+
+        def call(name, *a):
+            key = self.names.get(name)
+            if key is None:
+                return inner(name, *a)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
-            out = fn(*a, **k)
+            inner(name, *a)
             e.record()
-            self.pairs.setdefault(name, []).append((s, e))
-            return out
-        return timed
+            self.pairs.setdefault(key, []).append((s, e))
+        native.call = call
 
     def reset(self):
         self.pairs = {}
@@ -94,14 +101,18 @@ def cpu_baseline(a, args):
     PPM+loss forward+backward for one full batch; reported as hot-path images/s."""
     from oracle import pixpro_oracle as O
     from contrast.synthetic import make_batch
-    torch.set_num_threads(os.cpu_count())
+    # the box exposes every host core but a 1-GPU job owns a share of them: use the affinity mask, capped
+    threads = max(1, min(len(os.sched_getaffinity(0)), int(os.environ.get("PIXPRO_CPU_THREADS", "16"))))
+    torch.set_num_threads(threads)
     nf = a.cpu_flow_images
     data = make_batch(nf, image_size=8, n_frames=a.n_frames, device="cpu", seed=99)
     _, lo_f, lo_b = data[5]
     size = (720, 1280)
-    t0 = time.perf_counter()
-    ff, fb = O.apply_optical_flow_file(lo_f, lo_b, size, True, 0.01, 0.5)
-    t_flow = (time.perf_counter() - t0) / nf
+    with O.aten_samplers():     # the ATen kernels the reference calls (bit-identical to the explicit restatement)
+        O.apply_optical_flow_file(lo_f[:1], lo_b[:1], size, True, 0.01, 0.5)
+        t0 = time.perf_counter()
+        ff, fb = O.apply_optical_flow_file(lo_f, lo_b, size, True, 0.01, 0.5)
+        t_flow = (time.perf_counter() - t0) / nf
     N, C, G = a.batch, 256, a.image_size // 32
     gen = torch.Generator().manual_seed(5)
     big = make_batch(N, image_size=8, n_frames=2, device="cpu", seed=98, with_flow=False)
@@ -117,15 +128,16 @@ def cpu_baseline(a, args):
         t0 = time.perf_counter()
         A = [c1, [flow_f, size, mask_f]]
         B = [c2, [flow_b, size, mask_b]]
-        l1 = O.ppm_loss(xs[0], xs[1], ks[1], A, B, 2.0, 0.0, 0.7, True)[0]
-        l2 = O.ppm_loss(xs[2], xs[3], ks[0], B, A, 2.0, 0.0, 0.7, True)[0]
+        with O.aten_samplers():
+            l1 = O.ppm_loss(xs[0], xs[1], ks[1], A, B, 2.0, 0.0, 0.7, True)[0]
+            l2 = O.ppm_loss(xs[2], xs[3], ks[0], B, A, 2.0, 0.0, 0.7, True)[0]
         (l1 + l2).backward()
         t_ppm += time.perf_counter() - t0
         reps += 1
     t_ppm = t_ppm / reps / N
     return {"value": round(1.0 / (t_flow + t_ppm), 2), "unit": "images/s (hot path only: flow prep + PPM/loss fwd+bwd)",
-            "cores": os.cpu_count(), "kind": "port",
-            "sample": f"oracle/pixpro_oracle.py, torch-CPU fp32, {os.cpu_count()} threads: flow prep nframe={a.n_frames} "
+            "cores": threads, "kind": "port",
+            "sample": f"oracle/pixpro_oracle.py (ATen samplers), torch-CPU fp32, {threads} threads: flow prep nframe={a.n_frames} "
                       f"720x1280 on {nf} images ({t_flow * 1e3:.1f} ms/img) + PPM/loss fwd+bwd on {N} images x{reps} "
                       f"({t_ppm * 1e3:.3f} ms/img); encoders excluded",
             "flow_ms_per_image": round(t_flow * 1e3, 3), "ppm_ms_per_image": round(t_ppm * 1e3, 4)}
@@ -151,14 +163,15 @@ def main():
     torch.backends.cudnn.benchmark = bool(int(os.environ.get("PIXPRO_MIOPEN_FIND", "0")))
     torch.manual_seed(1234 + rank)
     loader = SyntheticLoader(a.steps + a.warmup, a.batch, pool=2, image_size=a.image_size, n_frames=a.n_frames,
-                             frame_hw=(720, 1280), device=dev, seed=1234 + rank)
+                             frame_hw=(720, 1280), device=dev, seed=1234 + rank, channels_last=a.channels_last)
     model, optimizer = main_pretrain.build_model(args, dev)
     scheduler = get_scheduler(optimizer, 70000 // (a.batch * world), args)
     model.train()
 
-    clock = KernelClock()
-    util.apply_optical_flow = clock.wrap("flow_prepare", util.apply_optical_flow)
-    ops.ppm_loss = clock.wrap("ppm_loss", ops.ppm_loss)
+    from contrast import _native
+    clock = KernelClock({"pixpro_flow_prepare": "flow_prepare", "pixpro_ppm_loss": "ppm_loss",
+                         "pixpro_lars_sgd_step": "lars_sgd_step", "pixpro_ema_update": "ema_update"})
+    clock.install(_native)
 
     it = iter(loader)
     note(rank, f"model built ({a.arch}, per-GPU batch {a.batch}); warm-up")
@@ -211,7 +224,13 @@ def main():
                                    "ms_per_launch": round(ms["ppm_loss"], 4),
                                    "algorithmic_flops_per_launch": int(f_ppm * a.batch),
                                    "hbm_frac": round(b_ppm * a.batch / t / HBM_PEAK, 4)}
-        dominant = max(kernels, key=lambda k: kernels[k]["ms_per_launch"]) if kernels else None
+        for extra, nbytes in (("lars_sgd_step", 7 * 33023552 * 4), ("ema_update", 3 * 32957888 * 4)):
+            if extra in ms:
+                t = ms[extra] * 1e-3
+                kernels[extra] = {"bound": "hbm", "achieved": round(nbytes / t / 1e9, 1), "peak": HBM_PEAK / 1e9,
+                                  "unit": "GB/s", "frac": round(nbytes / t / HBM_PEAK, 4), "traffic": None,
+                                  "ms_per_launch": round(ms[extra], 4), "algorithmic_bytes_per_launch": nbytes}
+        dominant = max(("flow_prepare", "ppm_loss"), key=lambda k: kernels[k]["ms_per_launch"]) if kernels else None
         out = {
             "metric": f"pretrain images/sec (whole node), ResNet-50 PixPro+OF {a.image_size}^2, nframe={a.n_frames}",
             "value": round(a.batch * world * a.steps / elapsed, 2), "unit": "images/s", "n_gpus": world,
@@ -229,7 +248,7 @@ def main():
             note(rank, "timing the CPU oracle on a bounded sample")
             cb = cpu_baseline(a, args)
             out["cpu_baseline"] = cb
-            hot_ms = sum(ms.values())
+            hot_ms = ms.get("flow_prepare", 0.0) + ms.get("ppm_loss", 0.0)
             out["hot_path_gpu"] = {"images_per_s": round(a.batch / (hot_ms * 1e-3), 1),
                                    "ms_per_batch_fwd": round(hot_ms, 4),
                                    "note": "flow prep + fused PPM/loss fwd+bwd on the GPU, same unit as cpu_baseline"}

@@ -23,6 +23,24 @@ import torch
 
 EPS_NORM = 1e-12  # F.normalize default eps
 
+# The explicit samplers below are what parity is defined on.  For *timing* the CPU baseline (bench.py) the
+# same two operations can be delegated to the ATen kernels the reference itself calls (F.grid_sample,
+# F.interpolate): identical results on this build (tests/test_oracle_golden.py::test_aten_samplers_agree), and
+# the speed of the reference's own CPU path rather than of the gather-based restatement.
+_ATEN_SAMPLERS = False
+
+
+class aten_samplers:
+    """with aten_samplers(): ... -> bilinear_sample / upflow8 call torch's own CPU kernels."""
+
+    def __enter__(self):
+        global _ATEN_SAMPLERS
+        self.prev, _ATEN_SAMPLERS = _ATEN_SAMPLERS, True
+
+    def __exit__(self, *exc):
+        global _ATEN_SAMPLERS
+        _ATEN_SAMPLERS = self.prev
+
 
 # --------------------------------------------------------------------------------------
 # small helpers
@@ -59,6 +77,11 @@ def bilinear_sample(img, gx, gy):
     out = fma(se_val, n*w, fma(sw_val, n*e, fma(ne_val, s*w, nw_val*(s*e)))).
     Used at contrast/models/PixPro.py:64 and contrast/util.py:278,318,322.
     """
+    if _ATEN_SAMPLERS:
+        lead = gx.shape[1:]
+        grid = torch.stack([gx, gy], -1).reshape(gx.shape[0], 1, -1, 2)
+        out = torch.nn.functional.grid_sample(img, grid, mode="bilinear", padding_mode="zeros", align_corners=True)
+        return out.reshape(img.shape[0], img.shape[1], *lead)
     Hf, Wf = img.shape[-2:]
     ix = (gx + 1) * ((Wf - 1) / 2)
     iy = (gy + 1) * ((Hf - 1) / 2)
@@ -262,6 +285,8 @@ def upflow8(flow):
     out = fma(d, w11, fma(c, w10, fma(a, w00, b*w01)))  with a,b = row y0 (x0,x1), c,d = row y1."""
     M, C, h, w = flow.shape
     Ho, Wo = 8 * h, 8 * w
+    if _ATEN_SAMPLERS:
+        return 8 * torch.nn.functional.interpolate(flow, size=(Ho, Wo), mode="bilinear", align_corners=True)
 
     def axis(n_in, n_out):
         scale = torch.tensor((n_in - 1) / (n_out - 1) if n_out > 1 else 0.0, dtype=torch.float32)

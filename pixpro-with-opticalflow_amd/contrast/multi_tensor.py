@@ -30,10 +30,22 @@ class _Table:
 _ema_table = _Table()
 
 
+def _dense(t):
+    return t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last))
+
+
 def _check(ts, what):
     for t in ts:
-        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
-            raise RuntimeError(f"{what}: needs contiguous fp32 CUDA tensors (no CPU fallback)")
+        if not (t.is_cuda and t.dtype == torch.float32 and _dense(t)):
+            raise RuntimeError(f"{what}: needs dense fp32 CUDA tensors (no CPU fallback)")
+
+
+def _same_layout(groups, what):
+    """element-wise kernels walk the storage linearly: every group must share the first one's strides"""
+    for g in groups[1:]:
+        for a, b in zip(groups[0], g):
+            if a.stride() != b.stride() or a.shape != b.shape:
+                raise RuntimeError(f"{what}: tensors of one slot differ in shape/strides {a.stride()} vs {b.stride()}")
 
 
 @torch.no_grad()
@@ -42,6 +54,7 @@ def ema_update(params_q, params_k, m):
     pq = [p.data for p in params_q]
     pk = [p.data for p in params_k]
     _check(pq + pk, "ema_update")
+    _same_layout([pq, pk], "ema_update")
     tab = _ema_table.get([pq, pk], pq[0].device)
     nv.call("pixpro_ema_update", nv.ptr(tab[0]), nv.ptr(tab[1]), nv.ptr(tab[2]), len(pq), float(m), nv.stream())
 
@@ -68,7 +81,8 @@ class LarsSgdStep:
         for p in self.params:
             if p.grad is None:
                 raise RuntimeError("LarsSgdStep: every parameter needs a gradient")
-            grads.append(p.grad if p.grad.is_contiguous() else p.grad.contiguous())
+            grads.append(p.grad if p.grad.stride() == p.stride() else p.grad.contiguous(
+                memory_format=torch.channels_last if p.dim() == 4 and not p.is_contiguous() else torch.contiguous_format))
         tab = self.table.get([[p.data for p in self.params], grads, self.bufs], self.params[0].device)
         nv.call("pixpro_lars_sgd_step", nv.ptr(tab[0]), nv.ptr(tab[1]), nv.ptr(tab[2]), nv.ptr(tab[3]),
                 nv.ptr(self.wd), nv.ptr(self.adapt), len(self.params), float(lr), float(self.momentum),

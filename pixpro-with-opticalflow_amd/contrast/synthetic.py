@@ -45,12 +45,15 @@ def smooth_noise(shape, sigma, gen, device):
 
 
 def make_batch(n, image_size=224, n_frames=2, frame_hw=(720, 1280), seed=1234, device="cuda", sigma=0.5,
-               flow_up=True, with_flow=True):
+               flow_up=True, with_flow=True, channels_last=False):
     Ho, Wo = frame_hw
     gen = torch.Generator(device=device).manual_seed(seed)
     rng = random.Random(seed)
     im1 = torch.randn(n, 3, image_size, image_size, generator=gen, device=device)
     im2 = torch.randn(n, 3, image_size, image_size, generator=gen, device=device)
+    if channels_last:
+        im1 = im1.contiguous(memory_format=torch.channels_last)
+        im2 = im2.contiguous(memory_format=torch.channels_last)
     coord1 = crop_coords(n, Wo, Ho, rng).to(device)
     coord2 = crop_coords(n, Wo, Ho, rng).to(device)
     index = torch.arange(n, device=device)

@@ -143,7 +143,7 @@ def main(args, device):
     size = args.image_size if isinstance(args.image_size, int) else args.image_size[0]
     loader = SyntheticLoader(args.steps_per_epoch, args.batch_size, image_size=size, n_frames=max(args.n_frames, 2),
                              frame_hw=tuple(args.frame_size), device=device, flow_up=args.flow_up,
-                             with_flow=args.use_flow, seed=1234 + (dist.get_rank() if dist.is_initialized() else 0))
+                             with_flow=args.use_flow, channels_last=getattr(args, "channels_last", False), seed=1234 + (dist.get_rank() if dist.is_initialized() else 0))
     model, optimizer = build_model(args, device)
     scheduler = get_scheduler(optimizer, len(loader), args)
     if args.pretrained_model:

@@ -186,3 +186,22 @@ def test_lars_trajectory():
             wd = g["weight_decay"] if adapt else 0.0
             p[i], buf[i] = O.lars_sgd_step(p[i], g[f"g{s}_{i}"], buf[i], g["lr"], g["momentum"], wd, adapt)
             assert torch.allclose(p[i], g[f"p{s + 1}_{i}"], rtol=1e-6, atol=1e-7)
+
+
+def test_aten_samplers_agree():
+    """The timing variant of the oracle (ATen samplers, used only by bench.py's cpu_baseline) is bit-identical
+    to the explicit restatement."""
+    g = load_golden("applyflow_f6up")
+    ref = O.apply_optical_flow_file(g["flow_fwds"], g["flow_bwds"], g["size"], True, 0.01, 0.5)
+    with O.aten_samplers():
+        fast = O.apply_optical_flow_file(g["flow_fwds"], g["flow_bwds"], g["size"], True, 0.01, 0.5)
+    for a, b in zip(ref, fast):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2])
+    g = load_golden("regloss_flowmask7")
+    size = tuple(int(s) for s in g["size"])
+    a = [g["coord_q"], [g["flow"], size, g["mask"]]]
+    b = [g["coord_k"], None]
+    l0, (n0, _) = O.regression_loss(g["q"], g["k"], a, b, 0.7)
+    with O.aten_samplers():
+        l1, (n1, _) = O.regression_loss(g["q"], g["k"], a, b, 0.7)
+    assert torch.equal(n0, n1) and l0.item() == l1.item()
