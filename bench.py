@@ -150,8 +150,13 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
-        dist.init_process_group(backend="nccl", init_method="env://")   # RCCL
+    if world > 1 or os.environ.get("PIXPRO_FORCE_DDP") == "1":
+        # RCCL.  PIXPRO_FORCE_DDP=1 exercises the DDP wrapper with a one-rank group on a single GPU.
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        dist.init_process_group(backend="nccl", init_method="env://")
     import main_pretrain
     from contrast import ops, util
     from contrast.lr_scheduler import get_scheduler
@@ -253,7 +258,7 @@ def main():
                                    "ms_per_batch_fwd": round(hot_ms, 4),
                                    "note": "flow prep + fused PPM/loss fwd+bwd on the GPU, same unit as cpu_baseline"}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

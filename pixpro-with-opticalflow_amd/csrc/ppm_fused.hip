@@ -86,24 +86,31 @@ __device__ __forceinline__ Smem carve(float* base, int C, int P) {
   return s;
 }
 
-// HBM -> registers (issue only) and registers -> LDS of one [C][P] tile (count % 4 == 0, 16-B aligned)
-struct Prefetch {
-  float4 r[PF];
-};
-__device__ __forceinline__ void pf_issue(Prefetch& p, const float* __restrict__ src, int count) {
-#pragma unroll
-  for (int i = 0; i < PF; ++i) {
-    const int e = (threadIdx.x + i * NTHREADS) * 4;
-    if (e < count) p.r[i] = *reinterpret_cast<const float4*>(src + e);
-  }
-}
-__device__ __forceinline__ void pf_commit(const Prefetch& p, float* __restrict__ dst, int count) {
-#pragma unroll
-  for (int i = 0; i < PF; ++i) {
-    const int e = (threadIdx.x + i * NTHREADS) * 4;
-    if (e < count) *reinterpret_cast<float4*>(dst + e) = p.r[i];
-  }
-}
+// HBM -> registers (issue only) and registers -> LDS of one [C][P] tile (count % 4 == 0, 16-B aligned).
+// Seven NAMED float4 per thread (an indexed array ends up in scratch memory, which turns the prefetch into a
+// synchronous round trip through HBM).  Loads are unconditional on a clamped index; the commit is guarded.
+#define PF_DECL(p) float4 p##0, p##1, p##2, p##3, p##4, p##5, p##6
+#define PF_ISSUE(p, src, count)                                                    \
+  do {                                                                             \
+    const float4* s4_ = reinterpret_cast<const float4*>(src);                      \
+    const int n4_ = (count) / 4 - 1, t_ = threadIdx.x;                             \
+    p##0 = s4_[min(t_, n4_)];                 p##1 = s4_[min(t_ + NTHREADS, n4_)];     \
+    p##2 = s4_[min(t_ + 2 * NTHREADS, n4_)];  p##3 = s4_[min(t_ + 3 * NTHREADS, n4_)]; \
+    p##4 = s4_[min(t_ + 4 * NTHREADS, n4_)];  p##5 = s4_[min(t_ + 5 * NTHREADS, n4_)]; \
+    p##6 = s4_[min(t_ + 6 * NTHREADS, n4_)];                                       \
+  } while (0)
+#define PF_COMMIT(p, dst, count)                                                   \
+  do {                                                                             \
+    float4* d4_ = reinterpret_cast<float4*>(dst);                                  \
+    const int n4_ = (count) / 4, t_ = threadIdx.x;                                 \
+    if (t_ < n4_) d4_[t_] = p##0;                                                  \
+    if (t_ + NTHREADS < n4_) d4_[t_ + NTHREADS] = p##1;                            \
+    if (t_ + 2 * NTHREADS < n4_) d4_[t_ + 2 * NTHREADS] = p##2;                    \
+    if (t_ + 3 * NTHREADS < n4_) d4_[t_ + 3 * NTHREADS] = p##3;                    \
+    if (t_ + 4 * NTHREADS < n4_) d4_[t_ + 4 * NTHREADS] = p##4;                    \
+    if (t_ + 5 * NTHREADS < n4_) d4_[t_ + 5 * NTHREADS] = p##5;                    \
+    if (t_ + 6 * NTHREADS < n4_) d4_[t_ + 6 * NTHREADS] = p##6;                    \
+  } while (0)
 __device__ __forceinline__ void store_tile(float* __restrict__ dst, const float* __restrict__ src, int count) {
   for (int e = threadIdx.x * 4; e < count; e += NTHREADS * 4)
     *reinterpret_cast<float4*>(dst + e) = *reinterpret_cast<const float4*>(src + e);
@@ -111,7 +118,7 @@ __device__ __forceinline__ void store_tile(float* __restrict__ dst, const float*
 
 // rn[j] = 1 / max(||buf[:,j]||, 1e-12) for j < P  (ends with a barrier)
 __device__ __forceinline__ void col_rnorms(const float* buf, float* rn, float* part, int C, int P) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int rows = C / NWAVES;
   float a0 = 0.f, a1 = 0.f;
   if (lane < P) {
@@ -136,7 +143,7 @@ __device__ __forceinline__ void col_rnorms(const float* buf, float* rn, float* p
 // Cross-wave column reduction of per-lane partials v[n] (column 16n + (lane&15)); ends with a barrier.
 template <int NT>
 __device__ __forceinline__ void col_reduce(float (&v)[NT], float* out, float* part) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
     float s = v[n];
@@ -176,9 +183,11 @@ __device__ __forceinline__ void gemm_cp(f32x4 (&acc)[MT][NT], int ksteps, FA fa,
 template <int NT>
 __device__ __forceinline__ void gemm_pp(f32x4& acc0, f32x4& acc1, const float* __restrict__ L,
                                         const float* __restrict__ R, int C, int P) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, lr = lane & 15,
+            lq = lane >> 4;
   const int t0 = wave, t1 = wave + NWAVES;
-  const bool has0 = t0 < NT * NT, has1 = t1 < NT * NT;
+  const bool has0 = (NT * NT >= NWAVES) || t0 < NT * NT;
+  const bool has1 = (NT * NT >= 2 * NWAVES) || t1 < NT * NT;    // compile-time true for the 4 x 4 tile grid
   if (!has0) return;
   const int i0 = min(16 * (t0 / NT) + lr, P - 1), j0 = min(16 * (t0 % NT) + lr, P - 1);
   const int i1 = has1 ? min(16 * (t1 / NT) + lr, P - 1) : i0, j1 = has1 ? min(16 * (t1 % NT) + lr, P - 1) : j0;
@@ -203,15 +212,18 @@ __device__ __forceinline__ void gemm_pp(f32x4& acc0, f32x4& acc1, const float* _
   }
 }
 
-template <int MT, int NT>
+// PC: compile-time P (49 for the 7x7 grid of 224^2 crops) so that every tile index folds into immediates;
+// 0 = run-time P.
+template <int MT, int NT, int PC>
 __global__ void __launch_bounds__(NTHREADS)
 ppm_fused_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* __restrict__ pos_num,
                  float* __restrict__ pos_mean) {
   extern __shared__ __attribute__((aligned(16))) float smem_raw[];
-  const int C = pb.C, P = pb.H * pb.W, N = pb.N;
+  const int C = 128 * MT, P = PC ? PC : pb.H * pb.W, N = pb.N;
   const int LR = lr_rows(P);
   const Smem sm = carve(smem_raw, C, P);
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lr = lane & 15,
+            lq = lane >> 4;
   const int b = blockIdx.x, dir = b / N, n = b % N;
   const pixpro_dir& dd = D.d[dir];
   const int tile = C * P;
@@ -227,9 +239,10 @@ ppm_fused_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* _
 
   STAMP(0);
   // ---- x -> B0 and v -> B1 in flight together; bin centres / flow taps meanwhile ----
-  Prefetch pfa, pfb;
-  pf_issue(pfa, gx, tile);
-  pf_issue(pfb, gv, tile);
+  PF_DECL(pfa);
+  PF_DECL(pfb);
+  PF_ISSUE(pfa, gx, tile);
+  PF_ISSUE(pfb, gv, tile);
   if (tid < 4) { sm.B0[tile + tid] = 0.f; sm.B1[tile + tid] = 0.f; }
   if (tid < 64) {
     float qx = 0.f, qy = 0.f, kx = 0.f, ky = 0.f;
@@ -256,9 +269,9 @@ ppm_fused_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* _
     }
     sm.qx[tid] = qx; sm.qy[tid] = qy; sm.kx[tid] = kx; sm.ky[tid] = ky; sm.valid[tid] = valid;
   }
-  pf_commit(pfa, sm.B0, tile);
-  pf_commit(pfb, sm.B1, tile);
-  pf_issue(pfa, gk, tile);          // k streams in under the mask / norm / S phases
+  PF_COMMIT(pfa, sm.B0, tile);
+  PF_COMMIT(pfb, sm.B1, tile);
+  PF_ISSUE(pfa, gk, tile);          // k streams in under the mask / norm / S phases
   __syncthreads();
   STAMP(1);
 
@@ -328,7 +341,7 @@ ppm_fused_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* _
     }
   }
   __syncthreads();                 // every wave is done with x in B0
-  pf_commit(pfa, sm.B0, tile);     // k -> B0
+  PF_COMMIT(pfa, sm.B0, tile);     // k -> B0
   STAMP(4);
 
   // ---- Y = v_hat A ----
@@ -432,7 +445,7 @@ ppm_fused_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* _
   if (!want_grad) return;
 
   // ---- dY -> B0 ; second read of x starts ----
-  pf_issue(pfa, gx, tile);
+  PF_ISSUE(pfa, gx, tile);
   {
     const float gs = pb.grad_scale * -2.f / (float)N / den;
 #pragma unroll
@@ -506,7 +519,7 @@ ppm_fused_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* _
       v[nn] = s;
     }
     col_reduce<NT>(v, sm.scol, sm.part);     // barrier: every wave is done reading dY from B0
-    pf_commit(pfa, sm.B0, tile);             // x -> B0 (second read)
+    PF_COMMIT(pfa, sm.B0, tile);             // x -> B0 (second read)
 #pragma unroll
     for (int nn = 0; nn < NT; ++nn) {
       const int j = 16 * nn + lr;
@@ -572,11 +585,11 @@ ppm_fused_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* _
   STAMP(15);
 }
 
-template <int MT, int NT>
+template <int MT, int NT, int PC = 0>
 int launch(const pixpro_problem& pb, const Dirs& D, float* loss_n, float* pos_num, float* pos_mean, hipStream_t st) {
   const int P = pb.H * pb.W;
   const size_t bytes = smem_floats(pb.C, P) * sizeof(float);
-  auto kern = ppm_fused_kernel<MT, NT>;
+  auto kern = ppm_fused_kernel<MT, NT, PC>;
   static thread_local size_t configured = 0;
   if (bytes > configured) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -607,6 +620,7 @@ int run_fused(const pixpro_problem& pb, const pixpro_dir* dirs, float* loss_n, f
   for (int d = 0; d < PIXPRO_MAX_DIRS; ++d) D.d[d] = dirs[d < pb.ndir ? d : 0];
   const int P = pb.H * pb.W;
   const int NT = (P + 15) / 16;
+  if (pb.C == 256 && P == 49) return launch<2, 4, 49>(pb, D, loss_n, pos_num, pos_mean, st);
   if (pb.C == 256) {
     switch (NT) {
       case 1: return launch<2, 1>(pb, D, loss_n, pos_num, pos_mean, st);
