@@ -41,12 +41,18 @@ __global__ void k_lars_norms(float* const* __restrict__ pp, const float* const* 
   const float* __restrict__ g = gp[t];
   const float w = wd[t];
   float sp = 0.f, sg = 0.f;
-  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)GX * TPB) {
-    const float pv = p[i];
-    const float gv = w > 0.f ? __builtin_fmaf(w, pv, g[i]) : g[i];
+  auto acc = [&](float pv, float gv0) {
+    const float gv = w > 0.f ? __builtin_fmaf(w, pv, gv0) : gv0;
     sp = __builtin_fmaf(pv, pv, sp);
     sg = __builtin_fmaf(gv, gv, sg);
+  };
+  const int64_t n4 = (((uintptr_t)p | (uintptr_t)g) & 15) == 0 ? n / 4 : 0;
+  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n4; i += (int64_t)GX * TPB) {
+    const float4 a = reinterpret_cast<const float4*>(p)[i];
+    const float4 b = reinterpret_cast<const float4*>(g)[i];
+    acc(a.x, b.x); acc(a.y, b.y); acc(a.z, b.z); acc(a.w, b.w);
   }
+  for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)GX * TPB) acc(p[i], g[i]);
   sp = wave_sum(sp); sg = wave_sum(sg);
   if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sp; red[1][threadIdx.x >> 6] = sg; }
   __syncthreads();
@@ -74,13 +80,26 @@ __global__ void k_lars_update(float* const* __restrict__ pp, const float* const*
     const float pn = sqrtf(norms2[2 * t]), gn = sqrtf(norms2[2 * t + 1]);
     if (pn > 0.f && gn > 0.f) ratio = trust * pn / (gn + eps);
   }
-  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)GX * TPB) {
-    const float pv = p[i];
-    float gv = w > 0.f ? __builtin_fmaf(w, pv, g[i]) : g[i];
+  auto upd = [&](float pv, float gv0, float bv0, float& pout, float& bout) {
+    float gv = w > 0.f ? __builtin_fmaf(w, pv, gv0) : gv0;
     gv = gv * ratio;
-    const float bv = first_step ? gv : buf[i] * momentum + gv;
+    bout = first_step ? gv : bv0 * momentum + gv;
+    pout = __builtin_fmaf(-lr, bout, pv);
+  };
+  const int64_t n4 = (((uintptr_t)p | (uintptr_t)g | (uintptr_t)buf) & 15) == 0 ? n / 4 : 0;
+  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n4; i += (int64_t)GX * TPB) {
+    float4 a = reinterpret_cast<float4*>(p)[i];
+    const float4 b = reinterpret_cast<const float4*>(g)[i];
+    float4 c = first_step ? make_float4(0.f, 0.f, 0.f, 0.f) : reinterpret_cast<float4*>(buf)[i];
+    upd(a.x, b.x, c.x, a.x, c.x); upd(a.y, b.y, c.y, a.y, c.y); upd(a.z, b.z, c.z, a.z, c.z); upd(a.w, b.w, c.w, a.w, c.w);
+    reinterpret_cast<float4*>(buf)[i] = c;
+    reinterpret_cast<float4*>(p)[i] = a;
+  }
+  for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)GX * TPB) {
+    float pv, bv;
+    upd(p[i], g[i], first_step ? 0.f : buf[i], pv, bv);
     buf[i] = bv;
-    p[i] = __builtin_fmaf(-lr, bv, pv);
+    p[i] = pv;
   }
 }
 

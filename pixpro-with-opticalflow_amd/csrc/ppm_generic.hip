@@ -43,18 +43,71 @@ __global__ void k_normalize(Dirs D, int which, const float* __restrict__ ws_src,
   }
 }
 
-// out[b,i,j] = sum_c A[b,c,i] * Bm[b,c,j]
-__global__ void k_gram(const float* __restrict__ A, const float* __restrict__ Bm, float* __restrict__ out, int B,
-                       int C, int P) {
-  const size_t idx = (size_t)blockIdx.x * TPB + threadIdx.x;
-  if (idx >= (size_t)B * P * P) return;
-  const int b = (int)(idx / ((size_t)P * P));
-  const int r = (int)(idx % ((size_t)P * P)), i = r / P, j = r % P;
-  const float* a = A + (size_t)b * C * P;
-  const float* bb = Bm + (size_t)b * C * P;
-  float acc = 0.f;
-  for (int c = 0; c < C; ++c) acc = __builtin_fmaf(a[(size_t)c * P + i], bb[(size_t)c * P + j], acc);
-  out[idx] = acc;
+// Batched strided matrix product on the exact-fp32 MFMA: Out[b][m][n] = sum_k A(b,m,k) * B(b,k,n) with
+// A(b,m,k) = A[b*sA + m*am + k*ak], B(b,k,n) = Bm[b*sB + k*bk + n*bn], Out[b*sO + m*on_m + n].
+// 64 x 64 output tile per 256-thread block (each wave 32 x 32 = 2 x 2 MFMA tiles), K in steps of 16 staged
+// through LDS as [k][m] / [k][n] (row stride 80 floats: conflict-free MFMA operand reads); out-of-range
+// rows/columns/k are zero-filled, so any M, N, K works.  Covers the P x P Gram products (K = C) and the
+// C x P propagation products (K = P) of the staged path.
+struct MM {
+  int M, N, K;
+  long sA, sB, sO;
+  int am, ak, bk, bn, om;
+};
+
+__global__ void __launch_bounds__(256) k_mm(const float* __restrict__ A, const float* __restrict__ Bm,
+                                             float* __restrict__ Out, MM q) {
+  constexpr int TS = 80;
+  __shared__ float As[16 * TS], Bs[16 * TS];
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lr = lane & 15,
+            lq = lane >> 4;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  const float* a = A + (long)blockIdx.z * q.sA;
+  const float* bb = Bm + (long)blockIdx.z * q.sB;
+  float* o = Out + (long)blockIdx.z * q.sO;
+  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // loader mapping: walk the unit-stride dimension with consecutive threads
+  const bool a_m_fast = q.am == 1, b_n_fast = q.bn == 1;
+  for (int k0 = 0; k0 < q.K; k0 += 16) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int idx = tid + e * 256;                       // 0 .. 1023
+      const int am_ = a_m_fast ? (idx & 63) : (idx >> 4), ak_ = a_m_fast ? (idx >> 6) : (idx & 15);
+      const int bn_ = b_n_fast ? (idx & 63) : (idx >> 4), bk_ = b_n_fast ? (idx >> 6) : (idx & 15);
+      const int gm = m0 + am_, gka = k0 + ak_, gn = n0 + bn_, gkb = k0 + bk_;
+      As[ak_ * TS + am_] = (gm < q.M && gka < q.K) ? a[(long)gm * q.am + (long)gka * q.ak] : 0.f;
+      Bs[bk_ * TS + bn_] = (gn < q.N && gkb < q.K) ? bb[(long)gkb * q.bk + (long)gn * q.bn] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      float av[2], bv[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        av[i] = As[(4 * ks + lq) * TS + wm + 16 * i + lr];
+        bv[i] = Bs[(4 * ks + lq) * TS + wn + 16 * i + lr];
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = mfma16(av[i], bv[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int gm = m0 + wm + 16 * i + 4 * lq + r, gn = n0 + wn + 16 * j + lr;
+        if (gm < q.M && gn < q.N) o[(long)gm * q.om + gn] = acc[i][j][r];
+      }
 }
 
 __global__ void k_powmap(const float* __restrict__ S, float* __restrict__ A, float* __restrict__ Dm, size_t n,
@@ -65,21 +118,6 @@ __global__ void k_powmap(const float* __restrict__ S, float* __restrict__ A, flo
   pow_map(S[idx], p, clampv, a, d);
   A[idx] = a;
   if (Dm) Dm[idx] = d;
-}
-
-// trans == 0: out[b,c,o] = sum_s In[b,c,s] * Mt[b,o,s];  trans == 1: ... * Mt[b,s,o]
-__global__ void k_apply(const float* __restrict__ In, const float* __restrict__ Mt, float* __restrict__ out, int B,
-                        int C, int P, int trans) {
-  const size_t idx = (size_t)blockIdx.x * TPB + threadIdx.x;
-  if (idx >= (size_t)B * C * P) return;
-  const int b = (int)(idx / ((size_t)C * P));
-  const int r = (int)(idx % ((size_t)C * P)), c = r / P, o = r % P;
-  const float* in = In + ((size_t)b * C + c) * P;
-  const float* m = Mt + (size_t)b * P * P;
-  float acc = 0.f;
-  if (trans) for (int s = 0; s < P; ++s) acc = __builtin_fmaf(in[s], m[(size_t)s * P + o], acc);
-  else       for (int s = 0; s < P; ++s) acc = __builtin_fmaf(in[s], m[(size_t)o * P + s], acc);
-  out[idx] = acc;
 }
 
 // Per (b,i): flow-displaced q centre + validity; per (b,j): k centre; per b: max bin diagonal.
@@ -265,6 +303,21 @@ size_t generic_workspace_bytes(const pixpro_problem& pb) {
   return 6 * al(B * R) + 5 * al(B * P) + 4 * al(B * Q) + al(B * 5 * P) + 2 * al(B) + 4096;
 }
 
+// out[b,i,j] = sum_c A[b,c,i] * Bm[b,c,j]
+#define GRAM(Ap, Bp, Op)                                                                          \
+  do {                                                                                            \
+    MM q_{P, P, C, (long)R, (long)R, (long)Q, 1, P, P, 1, P};                                       \
+    hipLaunchKernelGGL(k_mm, dim3((P + 63) / 64, (P + 63) / 64, B), dim3(256), 0, st, Ap, Bp, Op, q_); \
+    if (int e = check_launch("k_mm(gram)")) return e;                                             \
+  } while (0)
+// trans == 0: out[b,c,o] = sum_s In[b,c,s] * Mt[b,o,s];  trans == 1: ... * Mt[b,s,o]
+#define APPLY(Inp, Mtp, Op, trans)                                                                \
+  do {                                                                                            \
+    MM q_{C, P, P, (long)R, (long)Q, (long)R, P, 1, (trans) ? P : 1, (trans) ? 1 : P, P};           \
+    hipLaunchKernelGGL(k_mm, dim3((P + 63) / 64, (C + 63) / 64, B), dim3(256), 0, st, Inp, Mtp, Op, q_); \
+    if (int e = check_launch("k_mm(apply)")) return e;                                            \
+  } while (0)
+
 #define LAUNCH(kern, n, ...)                                                          \
   do {                                                                                \
     hipLaunchKernelGGL(kern, dim3(blocks_for(n)), dim3(TPB), 0, st, __VA_ARGS__);      \
@@ -307,7 +360,7 @@ int run_generic(const pixpro_problem& pb, const pixpro_dir* dirs, float* loss_n,
   if (mode == 1) {
     // q is given: loss_n = <q, K M^T>/den ; dq = g0/den * K M^T
     LAUNCH(k_normalize, (size_t)B * P, D, SRC_X, nullptr, Yh, nullptr, B, N, C, P, 0);
-    LAUNCH(k_apply, B * R, kh, M, G, B, C, P, 0);
+    APPLY(kh, M, G, 0);
     LAUNCH(k_coldot, (size_t)B * P, Yh, G, tcol, B, C, P);
     LAUNCH_B(k_loss_n, B, tcol, cnt, loss_n, P);
     LAUNCH_B(k_finalize, 1, loss_n, loss, B, N);
@@ -318,25 +371,25 @@ int run_generic(const pixpro_problem& pb, const pixpro_dir* dirs, float* loss_n,
   // forward: PPM
   LAUNCH(k_normalize, (size_t)B * P, D, SRC_X, nullptr, xh, nx, B, N, C, P, 1);
   LAUNCH(k_normalize, (size_t)B * P, D, SRC_V, nullptr, vh, nv, B, N, C, P, 1);
-  LAUNCH(k_gram, B * Q, xh, xh, dS, B, C, P);                     // S (in dS buffer)
+  GRAM(xh, xh, dS);                     // S (in dS buffer)
   LAUNCH(k_powmap, B * Q, dS, A, Dm, B * Q, pb.p, pb.clamp);
-  LAUNCH(k_apply, B * R, vh, A, T, B, C, P, 0);                   // Y = vh * A^T
+  APPLY(vh, A, T, 0);                   // Y = vh * A^T
   LAUNCH(k_normalize, (size_t)B * P, D, SRC_X, T, Yh, ny, B, N, C, P, 1);  // Yh, ny
   LAUNCH(k_copy_out, B * R, D, Yh, B, N, R);
   // loss
-  LAUNCH(k_apply, B * R, kh, M, G, B, C, P, 0);                   // G = kh * M^T
+  APPLY(kh, M, G, 0);                   // G = kh * M^T
   LAUNCH(k_coldot, (size_t)B * P, Yh, G, tcol, B, C, P);
   LAUNCH_B(k_loss_n, B, tcol, cnt, loss_n, P);
   LAUNCH_B(k_finalize, 1, loss_n, loss, B, N);
   if (!want_grad) return PIXPRO_OK;
   // backward
   LAUNCH(k_dy, B * R, G, Yh, tcol, ny, cnt, B, C, P, g0);         // G <- dY
-  LAUNCH(k_apply, B * R, G, A, T, B, C, P, 1);                    // dVh = dY * A
+  APPLY(G, A, T, 1);                    // dVh = dY * A
   LAUNCH(k_coldot, (size_t)B * P, vh, T, scol, B, C, P);
   LAUNCH(k_project, B * R, D, 1, nullptr, T, vh, scol, nv, B, N, C, P);   // dv
-  LAUNCH(k_gram, B * Q, G, vh, M, B, C, P);                       // dA (in M buffer)
+  GRAM(G, vh, M);                       // dA (in M buffer)
   LAUNCH(k_symm, B * Q, M, Dm, dS, B, P);
-  LAUNCH(k_apply, B * R, xh, dS, T, B, C, P, 1);                  // dXh = xh * dSs
+  APPLY(xh, dS, T, 1);                  // dXh = xh * dSs
   LAUNCH(k_coldot, (size_t)B * P, xh, T, scol, B, C, P);
   LAUNCH(k_project, B * R, D, 0, nullptr, T, xh, scol, nx, B, N, C, P);   // dx
   return PIXPRO_OK;
@@ -364,20 +417,20 @@ int run_featprop(const pixpro_problem& pb, const float* x, const float* v, const
   (void)kh; (void)Yh; (void)ny; (void)tcol;
   LAUNCH(k_normalize, (size_t)B * P, D, SRC_X, nullptr, xh, nx, B, N, C, P, 1);
   LAUNCH(k_normalize, (size_t)B * P, D, SRC_V, nullptr, vh, nv, B, N, C, P, 1);
-  LAUNCH(k_gram, B * Q, xh, xh, dS, B, C, P);
+  GRAM(xh, xh, dS);
   LAUNCH(k_powmap, B * Q, dS, A, Dm, B * Q, pb.p, pb.clamp);
   if (!dY) {
-    LAUNCH(k_apply, B * R, vh, A, T, B, C, P, 0);
+    APPLY(vh, A, T, 0);
     LAUNCH(k_copy_out, B * R, D, T, B, N, R);
     return PIXPRO_OK;
   }
   hipMemcpyAsync(G, dY, B * R * sizeof(float), hipMemcpyDeviceToDevice, st);
-  LAUNCH(k_apply, B * R, G, A, T, B, C, P, 1);
+  APPLY(G, A, T, 1);
   LAUNCH(k_coldot, (size_t)B * P, vh, T, scol, B, C, P);
   LAUNCH(k_project, B * R, D, 1, nullptr, T, vh, scol, nv, B, N, C, P);
-  LAUNCH(k_gram, B * Q, G, vh, M, B, C, P);
+  GRAM(G, vh, M);
   LAUNCH(k_symm, B * Q, M, Dm, dS, B, P);
-  LAUNCH(k_apply, B * R, xh, dS, T, B, C, P, 1);
+  APPLY(xh, dS, T, 1);
   LAUNCH(k_coldot, (size_t)B * P, xh, T, scol, B, C, P);
   LAUNCH(k_project, B * R, D, 0, nullptr, T, xh, scol, nx, B, N, C, P);
   return PIXPRO_OK;
