@@ -31,6 +31,20 @@ HBM_PEAK = 8.0e12        # B/s, MI355X_MICROARCH.md
 MFMA_F32_PEAK = 157.3e12  # FLOP/s, MI355X_MICROARCH.md
 
 
+def pmc_traffic(kernel, a):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.json: FETCH_SIZE and
+    WRITE_SIZE collected separately, gfx950 corrections applied as the file's note says).  Only valid for the
+    configuration it was collected on; traffic scales linearly with the batch."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
+            t = json.load(fh)
+    except OSError:
+        return None
+    if a.image_size != 224 or a.n_frames != 2 or kernel not in t:
+        return None
+    return int(t[kernel]["hbm_bytes_per_image"] * a.batch)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -218,14 +232,21 @@ def main():
         if "flow_prepare" in ms:
             t = ms["flow_prepare"] * 1e-3
             kernels["flow_prepare"] = {"bound": "hbm", "achieved": round(b_flow * a.batch / t / 1e9, 1), "peak": HBM_PEAK / 1e9,
-                                       "unit": "GB/s", "frac": round(b_flow * a.batch / t / HBM_PEAK, 4), "traffic": None,
+                                       "unit": "GB/s", "frac": round(b_flow * a.batch / t / HBM_PEAK, 4),
+                                       "traffic": pmc_traffic("flow_prepare", a),
                                        "ms_per_launch": round(ms["flow_prepare"], 4),
-                                       "algorithmic_bytes_per_launch": int(b_flow * a.batch)}
+                                       "algorithmic_bytes_per_launch": int(b_flow * a.batch),
+                                       "compulsory_bytes_per_launch": int((F1 * A / 16 + 4.5 * A) * a.batch),
+                                       "frac_compulsory": round((F1 * A / 16 + 4.5 * A) * a.batch / t / HBM_PEAK, 4),
+                                       "note": "algorithmic bytes = SURVEY 8d B_flow (reference's unfused dense pipeline); "
+                                               "the fused launch moves only the compulsory bytes and is VALU-bound "
+                                               "(bit-exact double bilinear), see DESIGN.md 4.3"}
         if "ppm_loss" in ms:
             t = ms["ppm_loss"] * 1e-3
             kernels["ppm_loss"] = {"bound": "mfma", "achieved": round(f_ppm * a.batch / t / 1e12, 3),
                                    "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
-                                   "frac": round(f_ppm * a.batch / t / MFMA_F32_PEAK, 4), "traffic": None,
+                                   "frac": round(f_ppm * a.batch / t / MFMA_F32_PEAK, 4),
+                                   "traffic": pmc_traffic("ppm_loss", a),
                                    "ms_per_launch": round(ms["ppm_loss"], 4),
                                    "algorithmic_flops_per_launch": int(f_ppm * a.batch),
                                    "hbm_frac": round(b_ppm * a.batch / t / HBM_PEAK, 4)}

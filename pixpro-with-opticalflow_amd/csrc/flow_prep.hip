@@ -249,20 +249,31 @@ struct Win {
   int h, w;
 };
 
-// the 2x2 low-res neighbourhood (i0y..i0y+1) x (i0x..i0x+1), clamped at the borders, all four channels
-__device__ __forceinline__ void lo_quad(const Win& wn, int i0y, int i0x, float4& a, float4& b, float4& c, float4& d) {
-  const int ry = i0y - wn.wy0, rx = i0x - wn.wx0;
-  if (__builtin_expect((unsigned)ry < (unsigned)(WIN_H - 1) && (unsigned)rx < (unsigned)(WIN_W - 1), 1)) {
-    const int o = ry * WIN_W + rx;
-    a = win_cells[o]; b = win_cells[o + 1]; c = win_cells[o + WIN_W]; d = win_cells[o + WIN_W + 1];
-  } else {
-    const int x1 = min(i0x + 1, wn.w - 1), y1 = min(i0y + 1, wn.h - 1);
-    const unsigned o00 = i0y * wn.w + i0x, o01 = i0y * wn.w + x1, o10 = y1 * wn.w + i0x, o11 = y1 * wn.w + x1;
-    a = make_float4(wn.g[0][o00], wn.g[1][o00], wn.g[2][o00], wn.g[3][o00]);
-    b = make_float4(wn.g[0][o01], wn.g[1][o01], wn.g[2][o01], wn.g[3][o01]);
-    c = make_float4(wn.g[0][o10], wn.g[1][o10], wn.g[2][o10], wn.g[3][o10]);
-    d = make_float4(wn.g[0][o11], wn.g[1][o11], wn.g[2][o11], wn.g[3][o11]);
-  }
+// Lean axis of the x8 up-sampling for positions inside the image: src = dst*scale < n_in always, so ATen's
+// clamps of i0 and of the weight are no-ops; the +1 neighbour is left to the caller (replicated LDS window,
+// or an explicit clamp on the global path).
+struct AxF {
+  int i0;
+  float l0, l1;
+};
+__device__ __forceinline__ AxF axf(int dst, float scale) {
+  AxF a;
+  const float src = (float)dst * scale;
+  a.i0 = (int)src;
+  a.l1 = src - (float)a.i0;
+  a.l0 = 1.f - a.l1;
+  return a;
+}
+
+// the 2x2 low-res neighbourhood (i0y..i0y+1) x (i0x..i0x+1) from global memory, clamped at the borders
+__device__ __forceinline__ void lo_quad_global(const Win& wn, int i0y, int i0x, float4& a, float4& b, float4& c,
+                                               float4& d) {
+  const int x1 = min(i0x + 1, wn.w - 1), y1 = min(i0y + 1, wn.h - 1);
+  const unsigned o00 = i0y * wn.w + i0x, o01 = i0y * wn.w + x1, o10 = y1 * wn.w + i0x, o11 = y1 * wn.w + x1;
+  a = make_float4(wn.g[0][o00], wn.g[1][o00], wn.g[2][o00], wn.g[3][o00]);
+  b = make_float4(wn.g[0][o01], wn.g[1][o01], wn.g[2][o01], wn.g[3][o01]);
+  c = make_float4(wn.g[0][o10], wn.g[1][o10], wn.g[2][o10], wn.g[3][o10]);
+  d = make_float4(wn.g[0][o11], wn.g[1][o11], wn.g[2][o11], wn.g[3][o11]);
 }
 
 // 16 * (weighted sum) = 2 * upflow8 value: both scalings are exact
@@ -274,10 +285,10 @@ __device__ __forceinline__ float up8_x16(float a, float b, float c, float d, flo
   return 16.f * acc;
 }
 
-// validity of one pixel given its own flow (fx, fy); `opp` selects the opposite direction's channels
+// validity of one pixel given its own flow (fx, fy); OPP selects the opposite direction's channels
 // (0: fwd = .x/.y of the cell, 1: bwd = .z/.w)
-__device__ __forceinline__ bool fbc_up8(float fx, float fy, const Win& wn, int opp, const Up8Geom& g, float c0x,
-                                        float c0y) {
+template <int OPP>
+__device__ __forceinline__ bool fbc_up8(float fx, float fy, const Win& wn, const Up8Geom& g, float c0x, float c0y) {
   const float fnx = div_c(2.f * fx, g.wd), fny = div_c(2.f * fy, g.ht);
   const float c1x = c0x + fnx, c1y = c0y + fny;
   if (!((fabsf(c1x) < 1.f) && (fabsf(c1y) < 1.f))) return false;
@@ -285,24 +296,28 @@ __device__ __forceinline__ bool fbc_up8(float fx, float fy, const Win& wn, int o
   const float xw = floorf(ix), yn = floorf(iy);
   const float w = ix - xw, e = 1.f - w, n = iy - yn, s = 1.f - n;
   const int x0 = (int)xw, y0 = (int)yn;
-  const bool vx1 = x0 + 1 < g.Wf, vy1 = y0 + 1 < g.Hf;      // false only when the weight is exactly 0
-  const Up8Axis ax0 = up8_axis(x0, g.w, g.sx), ax1 = up8_axis(min(x0 + 1, g.Wf - 1), g.w, g.sx);
-  const Up8Axis ay0 = up8_axis(y0, g.h, g.sy), ay1 = up8_axis(min(y0 + 1, g.Hf - 1), g.h, g.sy);
+  // x0+1 == Wf (y0+1 == Hf) only when the weight w (n) is exactly 0: the clamped tap is finite and contributes 0
+  const AxF ax[2] = {axf(x0, g.sx), axf(min(x0 + 1, g.Wf - 1), g.sx)};
+  const AxF ay[2] = {axf(y0, g.sy), axf(min(y0 + 1, g.Hf - 1), g.sy)};
+  const int rx0 = ax[0].i0 - wn.wx0, rx1 = ax[1].i0 - wn.wx0, ry0 = ay[0].i0 - wn.wy0, ry1 = ay[1].i0 - wn.wy0;
+  const bool in_win = (rx0 >= 0) && (rx1 < WIN_W - 1) && (ry0 >= 0) && (ry1 < WIN_H - 1);
   float tx[4], ty[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
-    const Up8Axis& ay = (t & 2) ? ay1 : ay0;
-    const Up8Axis& ax = (t & 1) ? ax1 : ax0;
-    const float w00 = ay.l0 * ax.l0, w01 = ay.l0 * ax.l1, w10 = ay.l1 * ax.l0, w11 = ay.l1 * ax.l1;
+    const AxF& vy_ = ay[t >> 1];
+    const AxF& vx_ = ax[t & 1];
+    const float w00 = vy_.l0 * vx_.l0, w01 = vy_.l0 * vx_.l1, w10 = vy_.l1 * vx_.l0, w11 = vy_.l1 * vx_.l1;
     float4 a, b, c, d;
-    lo_quad(wn, ay.i0, ax.i0, a, b, c, d);
-    const bool ok = ((t & 1) ? vx1 : true) && ((t & 2) ? vy1 : true);
-    const float vx = div_c(opp ? up8_x16(a.z, b.z, c.z, d.z, w00, w01, w10, w11)
-                               : up8_x16(a.x, b.x, c.x, d.x, w00, w01, w10, w11), g.wd);
-    const float vy = div_c(opp ? up8_x16(a.w, b.w, c.w, d.w, w00, w01, w10, w11)
-                               : up8_x16(a.y, b.y, c.y, d.y, w00, w01, w10, w11), g.ht);
-    tx[t] = ok ? vx : 0.f;
-    ty[t] = ok ? vy : 0.f;
+    if (__builtin_expect(in_win, 1)) {
+      const int o = ((t >> 1) ? ry1 : ry0) * WIN_W + ((t & 1) ? rx1 : rx0);
+      a = win_cells[o]; b = win_cells[o + 1]; c = win_cells[o + WIN_W]; d = win_cells[o + WIN_W + 1];
+    } else {
+      lo_quad_global(wn, vy_.i0, vx_.i0, a, b, c, d);
+    }
+    tx[t] = div_c(OPP ? up8_x16(a.z, b.z, c.z, d.z, w00, w01, w10, w11)
+                      : up8_x16(a.x, b.x, c.x, d.x, w00, w01, w10, w11), g.wd);
+    ty[t] = div_c(OPP ? up8_x16(a.w, b.w, c.w, d.w, w00, w01, w10, w11)
+                      : up8_x16(a.y, b.y, c.y, d.y, w00, w01, w10, w11), g.ht);
   }
   const float nw = s * e, ne = s * w, sw = n * e, se = n * w;
   const float bx = __builtin_fmaf(tx[3], se, __builtin_fmaf(tx[2], sw, __builtin_fmaf(tx[1], ne, tx[0] * nw)));
@@ -335,17 +350,18 @@ k_prepare_up8(const float* __restrict__ lo_fwd, const float* __restrict__ lo_bwd
   __syncthreads();
   int badf = 0, badb = 0;
   if (y < g.Hf && xb < g.Wf) {
-    const Up8Axis ay = up8_axis(y, g.h, g.sy);
+    const AxF ay = axf(y, g.sy);
+    const int ory = (ay.i0 - wn.wy0) * WIN_W - wn.wx0;
     const float c0y = div_c(2.f * (float)y, g.ht) - 1.f;
     float ffx[PPX], ffy[PPX], fbx[PPX], fby[PPX];
     uint8_t mf[PPX], mb[PPX];
 #pragma unroll
     for (int i = 0; i < PPX; ++i) {
       const int x = min(xb + i, g.Wf - 1);
-      const Up8Axis ax = up8_axis(x, g.w, g.sx);
+      const AxF ax = axf(x, g.sx);
       const float w00 = ay.l0 * ax.l0, w01 = ay.l0 * ax.l1, w10 = ay.l1 * ax.l0, w11 = ay.l1 * ax.l1;
-      float4 a, b, c, d;
-      lo_quad(wn, ay.i0, ax.i0, a, b, c, d);
+      const int o = ory + ax.i0;                       // the block's own footprint is inside the window
+      const float4 a = win_cells[o], b = win_cells[o + 1], c = win_cells[o + WIN_W], d = win_cells[o + WIN_W + 1];
       const float fx = 0.5f * up8_x16(a.x, b.x, c.x, d.x, w00, w01, w10, w11);
       const float fy = 0.5f * up8_x16(a.y, b.y, c.y, d.y, w00, w01, w10, w11);
       const float bx = 0.5f * up8_x16(a.z, b.z, c.z, d.z, w00, w01, w10, w11);
@@ -354,8 +370,8 @@ k_prepare_up8(const float* __restrict__ lo_fwd, const float* __restrict__ lo_bwd
       mf[i] = mb[i] = 0;
       if (mask_fwd) {
         const float c0x = div_c(2.f * (float)x, g.wd) - 1.f;
-        mf[i] = fbc_up8(fx, fy, wn, 1, g, c0x, c0y) ? 1 : 0;
-        mb[i] = fbc_up8(bx, by, wn, 0, g, c0x, c0y) ? 1 : 0;
+        mf[i] = fbc_up8<1>(fx, fy, wn, g, c0x, c0y) ? 1 : 0;
+        mb[i] = fbc_up8<0>(bx, by, wn, g, c0x, c0y) ? 1 : 0;
         if (xb + i < g.Wf) { badf += 1 - mf[i]; badb += 1 - mb[i]; }
       }
     }
