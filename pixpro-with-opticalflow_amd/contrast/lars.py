@@ -81,13 +81,12 @@ class LARS(torch.optim.Optimizer):
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
-        self._build()
+        saved = {p: self.state[p].get('momentum_buffer') for g in self.param_groups for p in g['params']}
+        self._build()                      # fresh fused buffers (registered as the state's momentum_buffer)
         have = 0
         for p, b in zip(self._fused.params, self._fused.bufs):
-            saved = self.state[p].get('momentum_buffer')
-            if saved is not None and saved is not b:
-                b.copy_(saved)
-                self.state[p]['momentum_buffer'] = b
+            if saved.get(p) is not None:
+                b.copy_(saved[p])
                 have += 1
         if have:
             self._fused.first = False

@@ -118,3 +118,68 @@ def test_train_step_runs_and_learns(dev):
     assert not torch.equal(w0, model.value_transform.weight)
     assert not torch.equal(k0, model.projector_k.linear2.weight)
     assert info["mask_fwd"].dtype == torch.bool
+
+
+def test_checkpoint_resume_roundtrip(dev, tmp_path):
+    """save_checkpoint / load_checkpoint (main_pretrain.py:96-127 of the reference): model, LARS momentum buffers,
+    scheduler and the EMA step counter survive; the resumed run reproduces the next step bit for bit."""
+    import main_pretrain
+    from contrast import option
+    from contrast.lr_scheduler import get_scheduler
+    from contrast.synthetic import make_batch
+
+    def build():
+        args = option.parse_option(argv=["--model", "PixPro", "--arch", "resnet18", "--synthetic", "--use_flow",
+                                         "--use_flow_file", "--flow_up", "--alpha1", "0.01", "--alpha2", "0.5",
+                                         "--n-frames", "2", "--optimizer", "lars", "--base-lr", "1.0",
+                                         "--weight-decay", "1e-5", "--amp-opt-level", "O0", "--pixpro-p", "2",
+                                         "--pixpro-transform-layer", "1", "--batch-size", "4", "--epochs", "4",
+                                         "--warmup-epoch", "1", "--head-type", "early_return",
+                                         "--output-dir", str(tmp_path)])
+        args.num_instances = 16
+        torch.manual_seed(0)
+        model, opt = main_pretrain.build_model(args, dev)
+        return args, model, opt, get_scheduler(opt, 4, args)
+
+    data = make_batch(4, image_size=64, n_frames=2, frame_hw=(96, 128), device=dev)
+    args, model, opt, sched = build()
+    model.train()
+    for _ in range(2):
+        main_pretrain.train_step(model, opt, sched, data, args)
+    main_pretrain.save_checkpoint(args, 1, model, opt, sched)
+    loss_a, _, _ = main_pretrain.train_step(model, opt, sched, data, args)
+    w_a = model.value_transform.weight.detach().clone()
+
+    args2, model2, opt2, sched2 = build()
+    args2.resume = str(tmp_path / "current.pth")
+    main_pretrain.load_checkpoint(args2, model2, opt2, sched2)
+    assert args2.start_epoch == 2
+    model2.train()
+    model2.k = model.k - 1                      # the EMA counter one step before the saved step's successor
+    loss_b, _, _ = main_pretrain.train_step(model2, opt2, sched2, data, args2)
+    # MIOpen's weight-gradient kernels and the LARS norm reduction accumulate with float atomics: equal up to
+    # re-association, not bit for bit
+    assert abs(loss_a.item() - loss_b.item()) <= 1e-5 * max(1.0, abs(loss_a.item()))
+    assert torch.allclose(w_a, model2.value_transform.weight.detach(), rtol=1e-4, atol=1e-6)
+
+
+def test_public_featprop_and_instance_branch(dev):
+    """PixPro.featprop as a public method (autograd through the HIP op) and the optional instance branch."""
+    from contrast import resnet
+    from contrast.models import PixPro
+    from oracle import pixpro_oracle as O
+    model = PixPro(resnet.resnet18, cfg1_args(pixpro_ins_loss_weight=0.5)).to(dev).train()
+    feat = torch.randn(2, 256, 4, 4, device=dev, requires_grad=True)
+    Y = model.featprop(feat)
+    Y.square().sum().backward()
+    xr = feat.detach().cpu().requires_grad_(True)
+    w, b = model.value_transform.weight.detach().cpu(), model.value_transform.bias.detach().cpu()
+    Yo = O.featprop(xr, torch.nn.functional.conv2d(xr, w, b), 2.0, 0.0)
+    Yo.square().sum().backward()
+    close(Y, Yo.detach(), rel=1e-5)
+    close(feat.grad, xr.grad, rel=2e-4)
+    im = torch.randn(2, 3, 64, 64, device=dev)
+    c = torch.tensor([[0.1, 0.1, 0.6, 0.7, 0, 0, 0, 0, 320, 180]] * 2, device=dev)
+    loss, pos = model(im, im, c, c)
+    loss.backward()
+    assert torch.isfinite(loss).item() and model.projector_instance.linear2.weight.grad is not None
