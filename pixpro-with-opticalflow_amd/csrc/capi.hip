@@ -2,6 +2,7 @@
 // No torch types, no allocation, no synchronisation (include/pixpro_hip.h).
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -26,9 +27,25 @@ int check_launch(const char* what) {
 }
 
 // implemented in the kernel translation units
-bool fused_supported(const pixpro_problem& pb);
-int run_fused(const pixpro_problem& pb, const pixpro_dir* dirs, float* loss_n, float* pos_num, float* pos_mean,
-              hipStream_t st);
+bool fused_supported_w8(const pixpro_problem& pb);
+bool fused_supported_w16(const pixpro_problem& pb);
+int run_fused_w8(const pixpro_problem& pb, const pixpro_dir* dirs, float* loss_n, float* pos_num, float* pos_mean,
+                 hipStream_t st);
+int run_fused_w16(const pixpro_problem& pb, const pixpro_dir* dirs, float* loss_n, float* pos_num, float* pos_mean,
+                  hipStream_t st);
+// PIXPRO_FUSED_WAVES=16 selects the 1024-thread variant where the shape allows (A/B timing: 117 us vs 112 us at
+// N=256, i.e. no gain from more waves - the kernel is bound by its phase structure); default: 8 waves
+static int fused_waves_pref() {
+  static const int pref = [] { const char* e = getenv("PIXPRO_FUSED_WAVES"); return e ? atoi(e) : 8; }();
+  return pref;
+}
+static bool fused_supported(const pixpro_problem& pb) { return fused_supported_w16(pb) || fused_supported_w8(pb); }
+static int run_fused(const pixpro_problem& pb, const pixpro_dir* dirs, float* loss_n, float* pos_num, float* pos_mean,
+                     hipStream_t st) {
+  if (fused_supported_w16(pb) && (fused_waves_pref() == 16 || !fused_supported_w8(pb)))
+    return run_fused_w16(pb, dirs, loss_n, pos_num, pos_mean, st);
+  return run_fused_w8(pb, dirs, loss_n, pos_num, pos_mean, st);
+}
 size_t generic_workspace_bytes(const pixpro_problem& pb);
 int run_generic(const pixpro_problem& pb, const pixpro_dir* dirs, float* loss_n, float* pos_num, float* pos_mean,
                 float* loss, void* workspace, size_t ws_bytes, hipStream_t st, int mode);

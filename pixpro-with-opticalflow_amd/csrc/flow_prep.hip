@@ -404,6 +404,160 @@ k_prepare_up8(const float* __restrict__ lo_fwd, const float* __restrict__ lo_bwd
   }
 }
 
+// ---- multi-frame (F-1 > 1) production kernels -----------------------------------------------------
+// k_chain_up8: concat_flow over lazily up-sampled 1/8-resolution maps.  Same tiling / LDS-window / exact
+// constant-division scheme as k_prepare_up8; one window per flow of the chain (float2 cells), direction in
+// blockIdx.z.  A chain that drifts out of its block's window reads global memory; a tap that leaves the frame
+// contributes zero (grid_sample zeros padding).
+constexpr int CH_MAXF = 6;       // windows kept in LDS: 6 * 48 * 16 * 8 B = 36 KB
+__shared__ float2 chain_cells[CH_MAXF * WIN_H * WIN_W];
+
+__device__ __forceinline__ void chain_quad(const float* __restrict__ gx, const float* __restrict__ gy, int t, int wx0,
+                                           int wy0, int h, int w, int i0y, int i0x, float2& a, float2& b, float2& c,
+                                           float2& d) {
+  const int ry = i0y - wy0, rx = i0x - wx0;
+  if (__builtin_expect((unsigned)ry < (unsigned)(WIN_H - 1) && (unsigned)rx < (unsigned)(WIN_W - 1), 1)) {
+    const int o = (t * WIN_H + ry) * WIN_W + rx;
+    a = chain_cells[o]; b = chain_cells[o + 1]; c = chain_cells[o + WIN_W]; d = chain_cells[o + WIN_W + 1];
+  } else {
+    const int x1 = min(i0x + 1, w - 1), y1 = min(i0y + 1, h - 1);
+    const unsigned o00 = i0y * w + i0x, o01 = i0y * w + x1, o10 = y1 * w + i0x, o11 = y1 * w + x1;
+    a = make_float2(gx[o00], gy[o00]); b = make_float2(gx[o01], gy[o01]);
+    c = make_float2(gx[o10], gy[o10]); d = make_float2(gx[o11], gy[o11]);
+  }
+}
+
+__global__ void __launch_bounds__(PT_X* PT_Y)
+k_chain_up8(const float* __restrict__ lo_fwd, const float* __restrict__ lo_bwd, float* __restrict__ flow_fwd,
+            float* __restrict__ flow_bwd, int N, int F1, Up8Geom g) {
+  const int n = blockIdx.z >> 1, dir = blockIdx.z & 1;
+  const float* lo = (dir ? lo_bwd : lo_fwd) + (size_t)n * F1 * 2 * g.h * g.w;   // [F1][2][h][w]
+  float* out = (dir ? flow_bwd : flow_fwd) + (size_t)n * 2 * g.Hf * g.Wf;
+  const size_t hw = (size_t)g.h * g.w, HW = (size_t)g.Hf * g.Wf;
+  const int y = blockIdx.y * PT_Y + threadIdx.y;
+  const int xb = (blockIdx.x * PT_X + threadIdx.x) * PPX;
+  const int wx0 = axf(blockIdx.x * PT_X * PPX, g.sx).i0 - WIN_MX;
+  const int wy0 = axf(blockIdx.y * PT_Y, g.sy).i0 - WIN_MY;
+  for (int e = threadIdx.y * PT_X + threadIdx.x; e < F1 * WIN_H * WIN_W; e += PT_X * PT_Y) {
+    const int t = e / (WIN_H * WIN_W), r = (e / WIN_W) % WIN_H, c = e % WIN_W;
+    const unsigned o = min(max(wy0 + r, 0), g.h - 1) * g.w + min(max(wx0 + c, 0), g.w - 1);
+    chain_cells[e] = make_float2(lo[(size_t)t * 2 * hw + o], lo[(size_t)t * 2 * hw + hw + o]);
+  }
+  __syncthreads();
+  if (y >= g.Hf || xb >= g.Wf) return;
+  float ox[PPX], oy[PPX];
+#pragma unroll
+  for (int i = 0; i < PPX; ++i) {
+    const int x = min(xb + i, g.Wf - 1);
+    const float x0f = (float)x, y0f = (float)y;
+    float cx = x0f, cy = y0f;
+    for (int t = 0; t < F1; ++t) {
+      const float* gx = lo + (size_t)t * 2 * hw;
+      const float* gy = gx + hw;
+      const float nx = div_c(2.f * cx, g.wd) - 1.f, ny = div_c(2.f * cy, g.ht) - 1.f;   // normalize_coord
+      const float ix = (nx + 1.f) * g.hx, iy = (ny + 1.f) * g.hy;
+      const float xw = floorf(ix), yn = floorf(iy);
+      const float w = ix - xw, e = 1.f - w, nn = iy - yn, s = 1.f - nn;
+      const int tx0 = (xw > -2.f && xw < (float)(g.Wf + 1)) ? (int)xw : -2;
+      const int ty0 = (yn > -2.f && yn < (float)(g.Hf + 1)) ? (int)yn : -2;
+      const bool vx[2] = {tx0 >= 0 && tx0 < g.Wf, tx0 + 1 >= 0 && tx0 + 1 < g.Wf};
+      const bool vy[2] = {ty0 >= 0 && ty0 < g.Hf, ty0 + 1 >= 0 && ty0 + 1 < g.Hf};
+      const AxF ax[2] = {axf(min(max(tx0, 0), g.Wf - 1), g.sx), axf(min(max(tx0 + 1, 0), g.Wf - 1), g.sx)};
+      const AxF ay[2] = {axf(min(max(ty0, 0), g.Hf - 1), g.sy), axf(min(max(ty0 + 1, 0), g.Hf - 1), g.sy)};
+      float tvx[4], tvy[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const AxF& qy = ay[k >> 1];
+        const AxF& qx = ax[k & 1];
+        const float w00 = qy.l0 * qx.l0, w01 = qy.l0 * qx.l1, w10 = qy.l1 * qx.l0, w11 = qy.l1 * qx.l1;
+        float2 a, b, c, d;
+        chain_quad(gx, gy, t, wx0, wy0, g.h, g.w, qy.i0, qx.i0, a, b, c, d);
+        const bool ok = vx[k & 1] && vy[k >> 1];
+        tvx[k] = ok ? 0.5f * up8_x16(a.x, b.x, c.x, d.x, w00, w01, w10, w11) : 0.f;
+        tvy[k] = ok ? 0.5f * up8_x16(a.y, b.y, c.y, d.y, w00, w01, w10, w11) : 0.f;
+      }
+      const float nw = s * e, ne = s * w, sw = nn * e, se = nn * w;
+      const float fx = __builtin_fmaf(tvx[3], se, __builtin_fmaf(tvx[2], sw, __builtin_fmaf(tvx[1], ne, tvx[0] * nw)));
+      const float fy = __builtin_fmaf(tvy[3], se, __builtin_fmaf(tvy[2], sw, __builtin_fmaf(tvy[1], ne, tvy[0] * nw)));
+      cx = cx + fx; cy = cy + fy;
+    }
+    ox[i] = cx - x0f; oy[i] = cy - y0f;
+  }
+  float* p = out + (size_t)y * g.Wf + xb;
+  if (xb + PPX <= g.Wf && (g.Wf & 3) == 0) {
+    *reinterpret_cast<float4*>(p) = make_float4(ox[0], ox[1], ox[2], ox[3]);
+    *reinterpret_cast<float4*>(p + HW) = make_float4(oy[0], oy[1], oy[2], oy[3]);
+  } else {
+    for (int i = 0; i < PPX && xb + i < g.Wf; ++i) { p[i] = ox[i]; p[HW + i] = oy[i]; }
+  }
+}
+
+// k_fbc_pair: both consistency masks of dense composed flows in one launch (direction in blockIdx.z & 1), 4 pixels
+// per thread, 16 B flow loads, exact constant division; the opposite flow is gathered from HBM/L2.
+__device__ __forceinline__ bool fbc_dense(float fx, float fy, const float* __restrict__ bx_, const float* __restrict__ by_,
+                                          const Up8Geom& g, float c0x, float c0y) {
+  const float fnx = div_c(2.f * fx, g.wd), fny = div_c(2.f * fy, g.ht);
+  const float c1x = c0x + fnx, c1y = c0y + fny;
+  if (!((fabsf(c1x) < 1.f) && (fabsf(c1y) < 1.f))) return false;
+  const float ix = (c1x + 1.f) * g.hx, iy = (c1y + 1.f) * g.hy;
+  const float xw = floorf(ix), yn = floorf(iy);
+  const float w = ix - xw, e = 1.f - w, n = iy - yn, s = 1.f - n;
+  const int x0 = (int)xw, y0 = (int)yn;
+  const int x1 = min(x0 + 1, g.Wf - 1), y1 = min(y0 + 1, g.Hf - 1);   // clamped taps carry weight 0 (see fbc_up8)
+  const unsigned o00 = y0 * g.Wf + x0, o01 = y0 * g.Wf + x1, o10 = y1 * g.Wf + x0, o11 = y1 * g.Wf + x1;
+  const float tx0 = div_c(2.f * bx_[o00], g.wd), tx1 = div_c(2.f * bx_[o01], g.wd), tx2 = div_c(2.f * bx_[o10], g.wd),
+              tx3 = div_c(2.f * bx_[o11], g.wd);
+  const float ty0 = div_c(2.f * by_[o00], g.ht), ty1 = div_c(2.f * by_[o01], g.ht), ty2 = div_c(2.f * by_[o10], g.ht),
+              ty3 = div_c(2.f * by_[o11], g.ht);
+  const float nw = s * e, ne = s * w, sw = n * e, se = n * w;
+  const float bx = __builtin_fmaf(tx3, se, __builtin_fmaf(tx2, sw, __builtin_fmaf(tx1, ne, tx0 * nw)));
+  const float by = __builtin_fmaf(ty3, se, __builtin_fmaf(ty2, sw, __builtin_fmaf(ty1, ne, ty0 * nw)));
+  const float cx = fnx + bx, cy = fny + by;
+  const float cyc = cx * cx + cy * cy;
+  const float eps = g.alpha1 * ((fnx * fnx + fny * fny) + (bx * bx + by * by)) + g.a2;
+  return (cyc - eps) <= 0.f;
+}
+
+__global__ void __launch_bounds__(PT_X* PT_Y)
+k_fbc_pair(const float* __restrict__ flow_fwd, const float* __restrict__ flow_bwd, uint8_t* __restrict__ mask_fwd,
+           uint8_t* __restrict__ mask_bwd, int32_t* __restrict__ invalid, int N, Up8Geom g) {
+  const int n = blockIdx.z >> 1, dir = blockIdx.z & 1;
+  const size_t HW = (size_t)g.Hf * g.Wf;
+  const float* f = (dir ? flow_bwd : flow_fwd) + (size_t)n * 2 * HW;
+  const float* o = (dir ? flow_fwd : flow_bwd) + (size_t)n * 2 * HW;
+  uint8_t* mask = (dir ? mask_bwd : mask_fwd) + (size_t)n * HW;
+  const int y = blockIdx.y * PT_Y + threadIdx.y;
+  const int xb = (blockIdx.x * PT_X + threadIdx.x) * PPX;
+  int bad = 0;
+  if (y < g.Hf && xb < g.Wf) {
+    const size_t r = (size_t)y * g.Wf + xb;
+    const bool vec = xb + PPX <= g.Wf && (g.Wf & 3) == 0;
+    float fx[PPX], fy[PPX];
+    if (vec) {
+      const float4 a = *reinterpret_cast<const float4*>(f + r), b = *reinterpret_cast<const float4*>(f + HW + r);
+      fx[0] = a.x; fx[1] = a.y; fx[2] = a.z; fx[3] = a.w; fy[0] = b.x; fy[1] = b.y; fy[2] = b.z; fy[3] = b.w;
+    } else {
+      for (int i = 0; i < PPX; ++i) { const size_t q = (size_t)y * g.Wf + min(xb + i, g.Wf - 1); fx[i] = f[q]; fy[i] = f[HW + q]; }
+    }
+    const float c0y = div_c(2.f * (float)y, g.ht) - 1.f;
+    uint8_t m[PPX];
+#pragma unroll
+    for (int i = 0; i < PPX; ++i) {
+      const int x = min(xb + i, g.Wf - 1);
+      const float c0x = div_c(2.f * (float)x, g.wd) - 1.f;
+      m[i] = fbc_dense(fx[i], fy[i], o, o + HW, g, c0x, c0y) ? 1 : 0;
+      if (xb + i < g.Wf) bad += 1 - m[i];
+    }
+    if (vec) *reinterpret_cast<uchar4*>(mask + r) = make_uchar4(m[0], m[1], m[2], m[3]);
+    else for (int i = 0; i < PPX && xb + i < g.Wf; ++i) mask[r + i] = m[i];
+  }
+  if (invalid) {
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) bad += __shfl_xor(bad, s, 64);
+    if (threadIdx.x == 0 && bad) atomicAdd(&invalid[dir * N + n], bad);
+  }
+}
+
 // ---- K8: calc_mask_ratio -----------------------------------------------------------------
 __global__ void k_mask_ratio(const uint8_t* __restrict__ mask, float* __restrict__ ratio, int64_t pixels) {
   __shared__ int red[TPB / WAVE];
@@ -470,6 +624,17 @@ int run_fbc(const float* f, const float* b, uint8_t* mask, float* cycle, int N, 
   return PIXPRO_OK;
 }
 
+static Up8Geom make_geom(int h, int w, int Hf, int Wf, float alpha1, float a2) {
+  Up8Geom g;
+  g.h = h; g.w = w; g.Hf = Hf; g.Wf = Wf;
+  g.sy = h > 1 ? (float)(h - 1) / (float)(8 * h - 1) : 0.f;
+  g.sx = w > 1 ? (float)(w - 1) / (float)(8 * w - 1) : 0.f;
+  g.wd = make_divc((float)(Wf - 1)); g.ht = make_divc((float)(Hf - 1));
+  g.hx = (float)(Wf - 1) / 2.f; g.hy = (float)(Hf - 1) / 2.f;
+  g.alpha1 = alpha1; g.a2 = a2;
+  return g;
+}
+
 int run_flow_prepare(const float* lo_fwd, const float* lo_bwd, float* flow_fwd, float* flow_bwd, uint8_t* mask_fwd,
                      uint8_t* mask_bwd, int32_t* invalid, int N, int F1, int h, int w, int flow_up, float alpha1,
                      double alpha2, hipStream_t st) {
@@ -506,7 +671,19 @@ int run_flow_prepare(const float* lo_fwd, const float* lo_bwd, float* flow_fwd, 
     CHECKED("k_prepare_single");
     return PIXPRO_OK;
   }
-  // F-1 > 1: chains (up-sampling evaluated lazily, both directions in one launch), then masks
+  // F-1 > 1: chains (up-sampling evaluated lazily, both directions in one launch), then both masks in one launch
+  const bool grid_ok = 2 * N <= 65535 && (Hf + PT_Y - 1) / PT_Y <= 65535;
+  if (grid_ok && flow_up && F1 <= CH_MAXF) {
+    const Up8Geom g = make_geom(h, w, Hf, Wf, alpha1, a2);
+    dim3 grid((Wf + PT_X * PPX - 1) / (PT_X * PPX), (Hf + PT_Y - 1) / PT_Y, 2 * N);
+    hipLaunchKernelGGL(k_chain_up8, grid, dim3(PT_X, PT_Y), 0, st, lo_fwd, lo_bwd, flow_fwd, flow_bwd, N, F1, g);
+    CHECKED("k_chain_up8");
+    if (mask_fwd) {
+      hipLaunchKernelGGL(k_fbc_pair, grid, dim3(PT_X, PT_Y), 0, st, flow_fwd, flow_bwd, mask_fwd, mask_bwd, invalid, N, g);
+      CHECKED("k_fbc_pair");
+    }
+    return PIXPRO_OK;
+  }
   if (flow_up) {
     Up8Source sf{lo_fwd, F1, h, w}, sb{lo_bwd, F1, h, w};
     hipLaunchKernelGGL(k_chain<Up8Source>, dim3(blocks_for(n), 2), dim3(TPB), 0, st, sf, sb, flow_fwd, flow_bwd, F1,

@@ -20,8 +20,22 @@
 
 namespace pixpro {
 
+// The translation unit is compiled twice (Makefile): PIXPRO_NW = 8 (512-thread work-groups, C = 128 or 256) and
+// PIXPRO_NW = 16 (1024 threads, 4 waves per SIMD, C = 256: more waves to cover LDS / barrier latency inside the
+// single work-group a CU can hold).
+#ifndef PIXPRO_NW
+#define PIXPRO_NW 8
+#endif
+#define PIXPRO_CAT2(a, b) a##b
+#define PIXPRO_CAT(a, b) PIXPRO_CAT2(a, b)
+#define WFN(name) PIXPRO_CAT(name##_w, PIXPRO_NW)
+
 #ifdef PIXPRO_STAMPS   // diagnostic build only (tools/ppm_phase_stamps.py): wave 0 of block 0 stamps s_memtime
+#if PIXPRO_NW == 16
 __device__ unsigned long long g_stamps[64];
+#else
+extern __device__ unsigned long long g_stamps[64];
+#endif
 #define STAMP(i)                                                                            \
   do {                                                                                      \
     if (blockIdx.x == 0 && threadIdx.x == 0) g_stamps[i] = __builtin_amdgcn_s_memtime();    \
@@ -32,10 +46,10 @@ __device__ unsigned long long g_stamps[64];
 
 namespace {
 
-constexpr int NTHREADS = 512;
-constexpr int NWAVES = NTHREADS / WAVE;
-constexpr int LS = 80;    // row stride of the small P x P matrices (80 % 32 == 16: conflict-free row pairs)
-constexpr int PF = 7;     // float4 prefetch registers per thread: 7 * 512 * 4 >= 256 * 49
+constexpr int NWAVES = PIXPRO_NW;
+constexpr int NTHREADS = NWAVES * WAVE;
+constexpr int LS = 81;    // row stride of the small P x P matrices: odd, so rows AND columns (dS^T) spread over the banks
+constexpr int PF = PIXPRO_NW == 16 ? 4 : 7;   // float4 prefetch registers per thread: PF * NTHREADS * 4 >= 256 * 49
 constexpr int KU = 8;     // k-unroll of the K = C contractions (operand loads issued KU steps ahead)
 
 struct Smem {
@@ -51,12 +65,13 @@ struct Smem {
   float* nx2;    // [64] diag of the raw Gram matrix
   float* tcol;   // [64]
   float* scol;   // [64]
-  float* part;   // [NWAVES][64]
+  float* part0;  // [NWAVES][64] x2: scratch of the column reductions, used alternately
+  float* part1;
   float* qx;     // [64] each
   float* qy;
   float* kx;
   float* ky;
-  float* misc;   // [16]: diag, cnt, -, ..., [8 + w] = per-wave positive counts
+  float* misc;   // [32]: diag, cnt, -, ..., [8 + w] = per-wave positive counts
   unsigned long long* mbits;  // [64]
   int* valid;    // [64]
 };
@@ -64,7 +79,7 @@ struct Smem {
 __host__ __device__ inline int lr_rows(int P) { return (P + 3) / 4 * 4; }
 
 __host__ __device__ inline size_t smem_floats(int C, int P) {
-  return 2 * ((size_t)C * P + 4) + 3 * (size_t)lr_rows(P) * LS + 7 * 64 + NWAVES * 64 + 4 * 64 + 16 + 2 * 64 + 64;
+  return 2 * ((size_t)C * P + 4) + 3 * (size_t)lr_rows(P) * LS + 7 * 64 + 2 * NWAVES * 64 + 4 * 64 + 32 + 2 * 64 + 64;
 }
 
 __device__ __forceinline__ Smem carve(float* base, int C, int P) {
@@ -78,9 +93,9 @@ __device__ __forceinline__ Smem carve(float* base, int C, int P) {
   s.DS = p; p += LR * LS;
   s.rx = p; p += 64; s.rv = p; p += 64; s.rk = p; p += 64; s.ry = p; p += 64;
   s.nx2 = p; p += 64; s.tcol = p; p += 64; s.scol = p; p += 64;
-  s.part = p; p += NWAVES * 64;
+  s.part0 = p; p += NWAVES * 64; s.part1 = p; p += NWAVES * 64;
   s.qx = p; p += 64; s.qy = p; p += 64; s.kx = p; p += 64; s.ky = p; p += 64;
-  s.misc = p; p += 16;
+  s.misc = p; p += 32;
   s.mbits = (unsigned long long*)p; p += 2 * 64;
   s.valid = (int*)p;
   return s;
@@ -89,6 +104,25 @@ __device__ __forceinline__ Smem carve(float* base, int C, int P) {
 // HBM -> registers (issue only) and registers -> LDS of one [C][P] tile (count % 4 == 0, 16-B aligned).
 // Seven NAMED float4 per thread (an indexed array ends up in scratch memory, which turns the prefetch into a
 // synchronous round trip through HBM).  Loads are unconditional on a clamped index; the commit is guarded.
+#if PIXPRO_NW == 16     // 1024 threads: 4 float4 per thread cover 16,384 floats
+#define PF_DECL(p) float4 p##0, p##1, p##2, p##3
+#define PF_ISSUE(p, src, count)                                                    \
+  do {                                                                             \
+    const float4* s4_ = reinterpret_cast<const float4*>(src);                      \
+    const int n4_ = (count) / 4 - 1, t_ = threadIdx.x;                             \
+    p##0 = s4_[min(t_, n4_)];                 p##1 = s4_[min(t_ + NTHREADS, n4_)];     \
+    p##2 = s4_[min(t_ + 2 * NTHREADS, n4_)];  p##3 = s4_[min(t_ + 3 * NTHREADS, n4_)]; \
+  } while (0)
+#define PF_COMMIT(p, dst, count)                                                   \
+  do {                                                                             \
+    float4* d4_ = reinterpret_cast<float4*>(dst);                                  \
+    const int n4_ = (count) / 4, t_ = threadIdx.x;                                 \
+    if (t_ < n4_) d4_[t_] = p##0;                                                  \
+    if (t_ + NTHREADS < n4_) d4_[t_ + NTHREADS] = p##1;                            \
+    if (t_ + 2 * NTHREADS < n4_) d4_[t_ + 2 * NTHREADS] = p##2;                    \
+    if (t_ + 3 * NTHREADS < n4_) d4_[t_ + 3 * NTHREADS] = p##3;                    \
+  } while (0)
+#else
 #define PF_DECL(p) float4 p##0, p##1, p##2, p##3, p##4, p##5, p##6
 #define PF_ISSUE(p, src, count)                                                    \
   do {                                                                             \
@@ -111,6 +145,7 @@ __device__ __forceinline__ Smem carve(float* base, int C, int P) {
     if (t_ + 5 * NTHREADS < n4_) d4_[t_ + 5 * NTHREADS] = p##5;                    \
     if (t_ + 6 * NTHREADS < n4_) d4_[t_ + 6 * NTHREADS] = p##6;                    \
   } while (0)
+#endif
 __device__ __forceinline__ void store_tile(float* __restrict__ dst, const float* __restrict__ src, int count) {
   for (int e = threadIdx.x * 4; e < count; e += NTHREADS * 4)
     *reinterpret_cast<float4*>(dst + e) = *reinterpret_cast<const float4*>(src + e);
@@ -140,10 +175,11 @@ __device__ __forceinline__ void col_rnorms(const float* buf, float* rn, float* p
   __syncthreads();
 }
 
-// Cross-wave column reduction of per-lane partials v[n] (column 16n + (lane&15)); ends with a barrier.
+// Cross-wave column reduction with ONE barrier: on return every lane holds in v[n] the sum over all C rows of
+// its own column 16n + (lane & 15).  Consecutive calls must alternate between two scratch buffers.
 template <int NT>
-__device__ __forceinline__ void col_reduce(float (&v)[NT], float* out, float* part) {
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+__device__ __forceinline__ void col_reduce_reg(float (&v)[NT], float* part) {
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, lr = lane & 15;
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
     float s = v[n];
@@ -152,13 +188,13 @@ __device__ __forceinline__ void col_reduce(float (&v)[NT], float* out, float* pa
     if (lane < 16) part[wave * 64 + 16 * n + lane] = s;
   }
   __syncthreads();
-  if (threadIdx.x < 16 * NT) {
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
     float t = 0.f;
 #pragma unroll
-    for (int w = 0; w < NWAVES; ++w) t += part[w * 64 + threadIdx.x];
-    out[threadIdx.x] = t;
+    for (int w = 0; w < NWAVES; ++w) t += part[w * 64 + 16 * n + lr];
+    v[n] = t;
   }
-  __syncthreads();
 }
 
 // C x P contraction: acc[m][n] += sum_k Aop(m, k) * Bop(n, k), k in steps of 4 (8 MFMAs per step hide
@@ -219,7 +255,7 @@ __global__ void __launch_bounds__(NTHREADS)
 ppm_fused_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* __restrict__ pos_num,
                  float* __restrict__ pos_mean) {
   extern __shared__ __attribute__((aligned(16))) float smem_raw[];
-  const int C = 128 * MT, P = PC ? PC : pb.H * pb.W, N = pb.N;
+  const int C = 16 * NWAVES * MT, P = PC ? PC : pb.H * pb.W, N = pb.N;
   const int LR = lr_rows(P);
   const Smem sm = carve(smem_raw, C, P);
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lr = lane & 15,
@@ -300,7 +336,7 @@ ppm_fused_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* _
     sm.misc[1] = c;
   }
   STAMP(2);
-  col_rnorms(sm.B1, sm.rv, sm.part, C, P);            // (barriers inside also publish misc[1])
+  col_rnorms(sm.B1, sm.rv, sm.part0, C, P);           // (barriers inside also publish misc[1])
   STAMP(3);
 
   // ---- S_raw = x^T x ; rx from its diagonal ; S, A, D ----
@@ -357,6 +393,7 @@ ppm_fused_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* _
                   },
                   [&](int nn, int ks) { return sm.AA[(4 * ks + lq) * LS + 16 * nn + lr]; });
   STAMP(5);
+  float ry[NT];      // 1 / ||Y[:, i]|| of this lane's columns
   {
     float v[NT];
 #pragma unroll
@@ -368,22 +405,22 @@ ppm_fused_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* _
         for (int r = 0; r < 4; ++r) s = __builtin_fmaf(Y[m][nn][r], Y[m][nn][r], s);
       v[nn] = s;
     }
-    col_reduce<NT>(v, sm.tcol, sm.part);   // barriers inside also publish k in B0
+    col_reduce_reg<NT>(v, sm.part1);       // the barrier inside also publishes k in B0
+#pragma unroll
+    for (int nn = 0; nn < NT; ++nn) ry[nn] = 1.f / fmaxf(sqrtf(v[nn]), 1e-12f);
   }
-  if (tid < 64) sm.ry[tid] = 1.f / fmaxf(sqrtf(sm.tcol[tid < 16 * NT ? tid : 0]), 1e-12f);
   if (pb.normalize_k) {
-    col_rnorms(sm.B0, sm.rk, sm.part, C, P);
+    col_rnorms(sm.B0, sm.rk, sm.part0, C, P);
   } else {
     if (tid < 64) sm.rk[tid] = 1.f;
     __syncthreads();
   }
 #pragma unroll
   for (int nn = 0; nn < NT; ++nn) {
-    const float ryv = sm.ry[16 * nn + lr];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) Y[m][nn][r] = Y[m][nn][r] * ryv;
+      for (int r = 0; r < 4; ++r) Y[m][nn][r] = Y[m][nn][r] * ry[nn];
   }
   if (dd.pred) {
     float* gp = dd.pred + (size_t)n * tile;
@@ -417,6 +454,7 @@ ppm_fused_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* _
                     [&](int nn, int ks) { return ((rowbits[nn] >> (4 * ks)) & 1ull) ? 1.f : 0.f; });
   }
   STAMP(7);
+  float tc[NT];      // <Y_hat[:, i], G[:, i]> of this lane's columns
   {
     float v[NT];
 #pragma unroll
@@ -428,12 +466,16 @@ ppm_fused_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* _
         for (int r = 0; r < 4; ++r) s = __builtin_fmaf(Y[m][nn][r], G[m][nn][r], s);
       v[nn] = s;
     }
-    col_reduce<NT>(v, sm.tcol, sm.part);   // barrier: every wave is done reading k from B0
+    col_reduce_reg<NT>(v, sm.part1);       // barrier: every wave is done reading k from B0
+#pragma unroll
+    for (int nn = 0; nn < NT; ++nn) tc[nn] = v[nn];
   }
   const float cnt = sm.misc[1];
   const float den = cnt + 1e-6f;
   if (wave == 0) {
-    float t = lane < P ? sm.tcol[lane] : 0.f;
+    float t = 0.f;
+#pragma unroll
+    for (int nn = 0; nn < NT; ++nn) t += (lane < 16 && 16 * nn + lr < P) ? tc[nn] : 0.f;
     t = wave_sum(t);
     if (lane == 0) {
       loss_n[b] = t / den;
@@ -452,7 +494,7 @@ ppm_fused_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* _
     for (int nn = 0; nn < NT; ++nn) {
       const int i = 16 * nn + lr;
       if (i < P) {
-        const float ti = gs * sm.tcol[i], ryv = sm.ry[i];
+        const float ti = gs * tc[nn], ryv = ry[nn];
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -518,13 +560,13 @@ ppm_fused_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* _
         }
       v[nn] = s;
     }
-    col_reduce<NT>(v, sm.scol, sm.part);     // barrier: every wave is done reading dY from B0
+    col_reduce_reg<NT>(v, sm.part0);         // barrier: every wave is done reading dY from B0
     PF_COMMIT(pfa, sm.B0, tile);             // x -> B0 (second read)
 #pragma unroll
     for (int nn = 0; nn < NT; ++nn) {
       const int j = 16 * nn + lr;
       if (j < P) {
-        const float sj = sm.scol[j], rvj = sm.rv[j];
+        const float sj = v[nn], rvj = sm.rv[j];
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -566,12 +608,12 @@ ppm_fused_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* _
         }
       v[nn] = s;
     }
-    col_reduce<NT>(v, sm.scol, sm.part);     // barrier: every wave is done reading x from B0
+    col_reduce_reg<NT>(v, sm.part1);         // barrier: every wave is done reading x from B0
 #pragma unroll
     for (int nn = 0; nn < NT; ++nn) {
       const int j = 16 * nn + lr;
       if (j < P) {
-        const float sj = sm.scol[j], rxj = sm.rx[j];
+        const float sj = v[nn], rxj = sm.rx[j];
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -606,22 +648,22 @@ int launch(const pixpro_problem& pb, const Dirs& D, float* loss_n, float* pos_nu
 
 }  // namespace
 
-bool fused_supported(const pixpro_problem& pb) {
+bool WFN(fused_supported)(const pixpro_problem& pb) {
   const int P = pb.H * pb.W;
   if (P > 64 || P < 1) return false;
-  if (pb.C != 128 && pb.C != 256) return false;
+  if (pb.C != 16 * NWAVES && !(NWAVES == 8 && pb.C == 256)) return false;
   if ((size_t)pb.C * P > (size_t)PF * NTHREADS * 4) return false;
   return smem_floats(pb.C, P) * sizeof(float) <= 160 * 1024;
 }
 
-int run_fused(const pixpro_problem& pb, const pixpro_dir* dirs, float* loss_n, float* pos_num, float* pos_mean,
-              hipStream_t st) {
+int WFN(run_fused)(const pixpro_problem& pb, const pixpro_dir* dirs, float* loss_n, float* pos_num, float* pos_mean,
+                   hipStream_t st) {
   Dirs D;
   for (int d = 0; d < PIXPRO_MAX_DIRS; ++d) D.d[d] = dirs[d < pb.ndir ? d : 0];
   const int P = pb.H * pb.W;
   const int NT = (P + 15) / 16;
-  if (pb.C == 256 && P == 49) return launch<2, 4, 49>(pb, D, loss_n, pos_num, pos_mean, st);
-  if (pb.C == 256) {
+  if (pb.C == 32 * NWAVES) {   // two C-tiles per wave (8 waves, C = 256)
+    if (P == 49) return launch<2, 4, 49>(pb, D, loss_n, pos_num, pos_mean, st);
     switch (NT) {
       case 1: return launch<2, 1>(pb, D, loss_n, pos_num, pos_mean, st);
       case 2: return launch<2, 2>(pb, D, loss_n, pos_num, pos_mean, st);
@@ -629,6 +671,7 @@ int run_fused(const pixpro_problem& pb, const pixpro_dir* dirs, float* loss_n, f
       default: return launch<2, 4>(pb, D, loss_n, pos_num, pos_mean, st);
     }
   }
+  if (P == 49) return launch<1, 4, 49>(pb, D, loss_n, pos_num, pos_mean, st);
   switch (NT) {
     case 1: return launch<1, 1>(pb, D, loss_n, pos_num, pos_mean, st);
     case 2: return launch<1, 2>(pb, D, loss_n, pos_num, pos_mean, st);

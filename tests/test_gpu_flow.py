@@ -66,7 +66,8 @@ def test_apply_optical_flow_golden(dev, tag):
 
 
 @pytest.mark.parametrize("nfr,hw,sigma", [(2, (90, 160), 0.5), (6, (45, 80), 0.5), (3, (23, 37), 0.5),
-                                          (2, (45, 80), 12.0), (2, (17, 29), 3.0), (2, (2, 2), 0.3)])
+                                          (2, (45, 80), 12.0), (2, (17, 29), 3.0), (2, (2, 2), 0.3),
+                                          (4, (30, 40), 8.0), (8, (12, 20), 0.4)])
 def test_apply_optical_flow_vs_oracle_full_size(dev, nfr, hw, sigma):
     """BDD-sized (720x1280 for nframe 2) and ragged sizes against the oracle; flows bit-exact,
     masks exact."""

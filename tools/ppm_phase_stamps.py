@@ -19,8 +19,16 @@ def main():
     out = "/tmp/libpixpro_hip_stamps.so"
     srcs = [os.path.join(PKG, "csrc", f) for f in ("capi.hip", "ppm_fused.hip", "ppm_generic.hip", "flow_prep.hip",
                                                    "multi_tensor.hip")]
-    subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
-                    "-ffp-contract=off", "-DPIXPRO_STAMPS", "-fgpu-rdc", "-o", out] + srcs, check=True)
+    objs = []
+    base = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off",
+            "-DPIXPRO_STAMPS", "-fgpu-rdc"]
+    for src in srcs:
+        o = "/tmp/stamps_" + os.path.basename(src) + ".o"
+        subprocess.run(base + ["-c", src, "-o", o], check=True)
+        objs.append(o)
+    subprocess.run(base + ["-DPIXPRO_NW=16", "-c", srcs[1], "-o", "/tmp/stamps_w16.o"], check=True)
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-fgpu-rdc", "--hip-link", "-shared", "-fPIC", "-o", out]
+                   + objs + ["/tmp/stamps_w16.o"], check=True)
     from contrast import _native
     _native.LIB_PATH = out
     from contrast import ops
