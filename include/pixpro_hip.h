@@ -48,6 +48,8 @@ typedef struct pixpro_problem {
                           (PixPro.py:403,407); 0: k is already unit-norm */
   int32_t ndir;     /* 1 or 2 loss directions handled by one call */
   float grad_scale; /* upstream d(loss): grads are those of grad_scale * loss (normally 1) */
+  int32_t layout;   /* memory order of x, v, k, pred, dx, dv: 0 = [N,C,P] (NCHW-contiguous), 1 = [N,P,C] (NHWC, i.e.
+                       torch channels_last).  1 is accepted by pixpro_ppm_loss on the single-launch path only. */
 } pixpro_problem;
 
 /* Per-direction operands.  Direction d: q-side view (x,v), k-side momentum projection k.

@@ -23,7 +23,7 @@ _sz = ctypes.c_size_t
 class Problem(ctypes.Structure):
     _fields_ = [("N", _i32), ("C", _i32), ("H", _i32), ("W", _i32), ("Hf", _i32), ("Wf", _i32),
                 ("Ho", _i32), ("Wo", _i32), ("p", _f32), ("clamp", _f32), ("pos_ratio", _f32),
-                ("normalize_k", _i32), ("ndir", _i32), ("grad_scale", _f32)]
+                ("normalize_k", _i32), ("ndir", _i32), ("grad_scale", _f32), ("layout", _i32)]
 
 
 class Dir(ctypes.Structure):
@@ -92,8 +92,14 @@ def stream():
     return _vp(torch.cuda.current_stream().cuda_stream)
 
 
-def dev_f32(t, name, shape=None):
-    """Validate a device fp32 operand (the reference's implicit torch errors become explicit)."""
+def is_nhwc(t):
+    """4-D tensor stored channels_last (and not also NCHW-contiguous, as 1x1 grids are)."""
+    return t.dim() == 4 and not t.is_contiguous() and t.is_contiguous(memory_format=torch.channels_last)
+
+
+def dev_f32(t, name, shape=None, nhwc=False):
+    """Validate a device fp32 operand (the reference's implicit torch errors become explicit).  nhwc=True keeps /
+    makes the tensor channels_last-dense instead of NCHW-contiguous."""
     if not isinstance(t, torch.Tensor):
         raise RuntimeError(f"{name}: expected a tensor, got {type(t).__name__}")
     if not t.is_cuda:
@@ -103,6 +109,8 @@ def dev_f32(t, name, shape=None):
         raise RuntimeError(f"{name}: expected float32, got {t.dtype}")
     if shape is not None and tuple(t.shape) != tuple(shape):
         raise RuntimeError(f"{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
+    if nhwc:
+        return t if is_nhwc(t) else t.contiguous(memory_format=torch.channels_last)
     return t if t.is_contiguous() else t.contiguous()
 
 

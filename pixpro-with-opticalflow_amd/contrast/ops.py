@@ -38,20 +38,26 @@ class Direction:
         self.flow, self.mask, self.size = flow, mask, size
 
 
-def _problem(dirs, p, clamp, pos_ratio, normalize_k, grad_scale=1.0):
+def _problem(dirs, p, clamp, pos_ratio, normalize_k, grad_scale=1.0, allow_nhwc=False):
     d0 = dirs[0]
     N, C, H, W = d0.x.shape
     pb = nv.Problem()
     pb.N, pb.C, pb.H, pb.W = N, C, H, W
+    # channels_last activations are consumed in place by the single-launch kernel (no NCHW copies)
+    nhwc = False
+    if allow_nhwc and nv.is_nhwc(d0.x):
+        pb.layout, pb.ndir = 1, len(dirs)
+        nhwc = nv.load().pixpro_ppm_loss_workspace_bytes(ctypes.byref(pb)) == 0   # 0 <=> single-launch kernel applies
+    pb.layout = int(nhwc)
     pb.p, pb.clamp, pb.pos_ratio = float(p), float(clamp), float(pos_ratio)
     pb.normalize_k, pb.ndir, pb.grad_scale = int(bool(normalize_k)), len(dirs), float(grad_scale)
     keep = []
     cds = (nv.Dir * 2)()
     for i, d in enumerate(dirs):
         shape = (N, C, H, W)
-        x = nv.dev_f32(d.x, "x", shape)
-        v = nv.dev_f32(d.v, "v", shape) if d.v is not None else None
-        k = nv.dev_f32(d.k, "k", shape)
+        x = nv.dev_f32(d.x, "x", shape, nhwc)
+        v = nv.dev_f32(d.v, "v", shape, nhwc) if d.v is not None else None
+        k = nv.dev_f32(d.k, "k", shape, nhwc)
         cq = nv.dev_f32(d.coord_q, "coord_q", (N, 10))
         ck = nv.dev_f32(d.coord_k, "coord_k", (N, 10))
         flow = mask = None
@@ -88,7 +94,7 @@ class _PPMLoss(torch.autograd.Function):
         nd = len(dirs)
         for i, d in enumerate(dirs):
             d.x, d.v = xv[2 * i], xv[2 * i + 1]
-        pb, cds, keep = _problem(dirs, p, clamp, pos_ratio, normalize_k)
+        pb, cds, keep = _problem(dirs, p, clamp, pos_ratio, normalize_k, allow_nhwc=not generic)
         x0 = keep[0]
         dev = x0.device
         N = pb.N
@@ -96,8 +102,13 @@ class _PPMLoss(torch.autograd.Function):
         out = torch.empty(3 * nd * N + 1, dtype=torch.float32, device=dev)
         loss_n, pos_num, pos_mean = out[:nd * N], out[nd * N:2 * nd * N], out[2 * nd * N:3 * nd * N]
         loss = out[3 * nd * N:]
-        grads = torch.empty((2 * nd,) + tuple(x0.shape), dtype=torch.float32, device=dev) if want_grad else None
-        preds = torch.empty((nd,) + tuple(x0.shape), dtype=torch.float32, device=dev) if want_pred else None
+        def like_x(lead):
+            n_, c_, h_, w_ = x0.shape
+            if pb.layout:   # [lead, N, H, W, C] storage viewed as [lead, N, C, H, W]: every slice is channels_last
+                return torch.empty((lead, n_, h_, w_, c_), dtype=torch.float32, device=dev).permute(0, 1, 4, 2, 3)
+            return torch.empty((lead, n_, c_, h_, w_), dtype=torch.float32, device=dev)
+        grads = like_x(2 * nd) if want_grad else None
+        preds = like_x(nd) if want_pred else None
         for i in range(nd):
             if want_grad:
                 cds[i].dx, cds[i].dv = nv.ptr(grads[2 * i]), nv.ptr(grads[2 * i + 1])
@@ -130,7 +141,7 @@ class _PPMLoss(torch.autograd.Function):
         g = gloss.detach().to(torch.float32).reshape(1)
         applied = getattr(ctx, "applied", None)
         ratio = (g if applied is None else g / applied).contiguous()
-        nv.call("pixpro_scale_by_device_scalar", nv.ptr(grads), grads.numel(), nv.ptr(ratio), nv.stream())
+        nv.call("pixpro_scale_by_device_scalar", nv.ptr(grads), grads.numel(), nv.ptr(ratio), nv.stream())  # dense buffer
         ctx.applied = g.clone()
         return (None,) + tuple(grads[i] for i in range(2 * ctx.nd))
 

@@ -42,7 +42,7 @@ static int fused_waves_pref() {
 static bool fused_supported(const pixpro_problem& pb) { return fused_supported_w16(pb) || fused_supported_w8(pb); }
 static int run_fused(const pixpro_problem& pb, const pixpro_dir* dirs, float* loss_n, float* pos_num, float* pos_mean,
                      hipStream_t st) {
-  if (fused_supported_w16(pb) && (fused_waves_pref() == 16 || !fused_supported_w8(pb)))
+  if (pb.layout == 0 && fused_supported_w16(pb) && (fused_waves_pref() == 16 || !fused_supported_w8(pb)))
     return run_fused_w16(pb, dirs, loss_n, pos_num, pos_mean, st);
   return run_fused_w8(pb, dirs, loss_n, pos_num, pos_mean, st);
 }
@@ -79,6 +79,7 @@ int validate_problem(const pixpro_problem* pb, const pixpro_dir* dirs, bool need
   if (!pb || !dirs) return bad("null problem / dirs");
   if (pb->N < 1 || pb->C < 1 || pb->H < 1 || pb->W < 1) return bad("N, C, H, W must be positive");
   if (pb->ndir < 1 || pb->ndir > PIXPRO_MAX_DIRS) return bad("ndir must be 1 or 2");
+  if (pb->layout != 0 && pb->layout != 1) return bad("layout must be 0 (NCHW) or 1 (NHWC)");
   for (int d = 0; d < pb->ndir; ++d) {
     const pixpro_dir& q = dirs[d];
     if (!q.x || !q.k || !q.coord_q || !q.coord_k) return bad("x, k, coord_q, coord_k are required");
@@ -116,6 +117,7 @@ size_t pixpro_ppm_loss_generic_workspace_bytes(const pixpro_problem* pb) {
 int pixpro_ppm_loss_generic(const pixpro_problem* pb, const pixpro_dir* dirs, float* loss_n, float* pos_num,
                             float* pos_mean, float* loss, void* workspace, size_t workspace_bytes, void* stream) {
   if (int e = validate_problem(pb, dirs, true)) return e;
+  if (pb->layout != 0) return bad("the staged path takes NCHW tiles");
   if (!loss_n || !pos_num || !pos_mean || !loss || !workspace) return bad("null output / workspace");
   return run_generic(*pb, dirs, loss_n, pos_num, pos_mean, loss, workspace, workspace_bytes, (hipStream_t)stream, 0);
 }
@@ -130,6 +132,8 @@ int pixpro_ppm_loss(const pixpro_problem* pb, const pixpro_dir* dirs, float* los
     const uintptr_t bits = (uintptr_t)q.x | (uintptr_t)q.v | (uintptr_t)q.k | (uintptr_t)q.dx | (uintptr_t)q.dv;
     if (bits & 15) aligned = false;
   }
+  if (pb->layout == 1 && !(fused_supported_w8(*pb) && aligned))
+    return bad("NHWC tiles are handled by the single-launch kernel only (P <= 64, C in {128, 256}, 16-B aligned)");
   if (fused_supported(*pb) && aligned) {
     if (int e = run_fused(*pb, dirs, loss_n, pos_num, pos_mean, (hipStream_t)stream)) return e;
     return run_finalize(loss_n, loss, pb->N * pb->ndir, pb->N, (hipStream_t)stream);

@@ -146,6 +146,46 @@ __device__ __forceinline__ Smem carve(float* base, int C, int P) {
     if (t_ + 6 * NTHREADS < n4_) d4_[t_ + 6 * NTHREADS] = p##6;                    \
   } while (0)
 #endif
+// NHWC (channels_last) tiles: the sample is [P][C] in HBM.  A wave covers 8 pixels x 8 groups of 4 channels per
+// row-block (8 x 128-B segments per load / store instruction) and transposes through scalar LDS accesses into /
+// out of the same [C][P] LDS image the NCHW path uses.  8-wave build only; PF row-blocks of 8 pixels cover P <= 56.
+#if PIXPRO_NW == 8
+#define PFT_ISSUE(p, src, C4, P)                                                          \
+  do {                                                                                    \
+    const float4* s4_ = reinterpret_cast<const float4*>(src);                             \
+    const int ps_ = threadIdx.x & 7, c4_ = min((int)(threadIdx.x >> 3), (C4) - 1);        \
+    p##0 = s4_[min(ps_, (P) - 1) * (C4) + c4_];       p##1 = s4_[min(8 + ps_, (P) - 1) * (C4) + c4_];  \
+    p##2 = s4_[min(16 + ps_, (P) - 1) * (C4) + c4_];  p##3 = s4_[min(24 + ps_, (P) - 1) * (C4) + c4_]; \
+    p##4 = s4_[min(32 + ps_, (P) - 1) * (C4) + c4_];  p##5 = s4_[min(40 + ps_, (P) - 1) * (C4) + c4_]; \
+    p##6 = s4_[min(48 + ps_, (P) - 1) * (C4) + c4_];                                      \
+  } while (0)
+#define PFT_PUT_(v, blk, dst, C4, P)                                                      \
+  do {                                                                                    \
+    const int p_ = (blk) * 8 + (threadIdx.x & 7), c_ = 4 * (int)(threadIdx.x >> 3);       \
+    if (p_ < (P) && c_ < 4 * (C4)) {                                                      \
+      (dst)[c_ * (P) + p_] = v.x; (dst)[(c_ + 1) * (P) + p_] = v.y;                       \
+      (dst)[(c_ + 2) * (P) + p_] = v.z; (dst)[(c_ + 3) * (P) + p_] = v.w;                 \
+    }                                                                                     \
+  } while (0)
+#define PFT_COMMIT(p, dst, C4, P)                                                         \
+  do {                                                                                    \
+    PFT_PUT_(p##0, 0, dst, C4, P); PFT_PUT_(p##1, 1, dst, C4, P); PFT_PUT_(p##2, 2, dst, C4, P); \
+    PFT_PUT_(p##3, 3, dst, C4, P); PFT_PUT_(p##4, 4, dst, C4, P); PFT_PUT_(p##5, 5, dst, C4, P); \
+    PFT_PUT_(p##6, 6, dst, C4, P);                                                        \
+  } while (0)
+__device__ __forceinline__ void store_tile_nhwc(float* __restrict__ dst, const float* __restrict__ src, int C4, int P) {
+  const int ps = threadIdx.x & 7, c4 = threadIdx.x >> 3, c = 4 * c4;
+  if (c4 >= C4) return;
+#pragma unroll
+  for (int blk = 0; blk < 7; ++blk) {
+    const int p = blk * 8 + ps;
+    if (p < P)
+      reinterpret_cast<float4*>(dst)[p * C4 + c4] =
+          make_float4(src[c * P + p], src[(c + 1) * P + p], src[(c + 2) * P + p], src[(c + 3) * P + p]);
+  }
+}
+#endif
+
 __device__ __forceinline__ void store_tile(float* __restrict__ dst, const float* __restrict__ src, int count) {
   for (int e = threadIdx.x * 4; e < count; e += NTHREADS * 4)
     *reinterpret_cast<float4*>(dst + e) = *reinterpret_cast<const float4*>(src + e);
@@ -277,8 +317,20 @@ ppm_fused_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* _
   // ---- x -> B0 and v -> B1 in flight together; bin centres / flow taps meanwhile ----
   PF_DECL(pfa);
   PF_DECL(pfb);
-  PF_ISSUE(pfa, gx, tile);
-  PF_ISSUE(pfb, gv, tile);
+#if PIXPRO_NW == 8
+  const bool nhwc = pb.layout == 1;
+  const int C4 = C / 4;
+#define LOAD_TILE(p, src)  do { if (nhwc) PFT_ISSUE(p, src, C4, P); else PF_ISSUE(p, src, tile); } while (0)
+#define PUT_TILE(p, dst)   do { if (nhwc) PFT_COMMIT(p, dst, C4, P); else PF_COMMIT(p, dst, tile); } while (0)
+#define OUT_TILE(gdst, src) do { if (nhwc) store_tile_nhwc(gdst, src, C4, P); else store_tile(gdst, src, tile); } while (0)
+#else
+  const bool nhwc = false;
+#define LOAD_TILE(p, src)  PF_ISSUE(p, src, tile)
+#define PUT_TILE(p, dst)   PF_COMMIT(p, dst, tile)
+#define OUT_TILE(gdst, src) store_tile(gdst, src, tile)
+#endif
+  LOAD_TILE(pfa, gx);
+  LOAD_TILE(pfb, gv);
   if (tid < 4) { sm.B0[tile + tid] = 0.f; sm.B1[tile + tid] = 0.f; }
   if (tid < 64) {
     float qx = 0.f, qy = 0.f, kx = 0.f, ky = 0.f;
@@ -305,9 +357,9 @@ ppm_fused_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* _
     }
     sm.qx[tid] = qx; sm.qy[tid] = qy; sm.kx[tid] = kx; sm.ky[tid] = ky; sm.valid[tid] = valid;
   }
-  PF_COMMIT(pfa, sm.B0, tile);
-  PF_COMMIT(pfb, sm.B1, tile);
-  PF_ISSUE(pfa, gk, tile);          // k streams in under the mask / norm / S phases
+  PUT_TILE(pfa, sm.B0);
+  PUT_TILE(pfb, sm.B1);
+  LOAD_TILE(pfa, gk);               // k streams in under the mask / norm / S phases
   __syncthreads();
   STAMP(1);
 
@@ -377,7 +429,7 @@ ppm_fused_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* _
     }
   }
   __syncthreads();                 // every wave is done with x in B0
-  PF_COMMIT(pfa, sm.B0, tile);     // k -> B0
+  PUT_TILE(pfa, sm.B0);            // k -> B0
   STAMP(4);
 
   // ---- Y = v_hat A ----
@@ -431,7 +483,7 @@ ppm_fused_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* _
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int i = 16 * nn + lr;
-          if (i < P) gp[(size_t)crow(m, r) * P + i] = Y[m][nn][r];
+          if (i < P) gp[nhwc ? (size_t)i * C + crow(m, r) : (size_t)crow(m, r) * P + i] = Y[m][nn][r];
         }
   }
   STAMP(6);
@@ -487,7 +539,7 @@ ppm_fused_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* _
   if (!want_grad) return;
 
   // ---- dY -> B0 ; second read of x starts ----
-  PF_ISSUE(pfa, gx, tile);
+  LOAD_TILE(pfa, gx);
   {
     const float gs = pb.grad_scale * -2.f / (float)N / den;
 #pragma unroll
@@ -561,7 +613,7 @@ ppm_fused_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* _
       v[nn] = s;
     }
     col_reduce_reg<NT>(v, sm.part0);         // barrier: every wave is done reading dY from B0
-    PF_COMMIT(pfa, sm.B0, tile);             // x -> B0 (second read)
+    PUT_TILE(pfa, sm.B0);                    // x -> B0 (second read)
 #pragma unroll
     for (int nn = 0; nn < NT; ++nn) {
       const int j = 16 * nn + lr;
@@ -576,7 +628,7 @@ ppm_fused_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* _
   }
   __syncthreads();
   STAMP(12);
-  store_tile(dd.dv + (size_t)n * tile, sm.B1, tile);
+  OUT_TILE(dd.dv + (size_t)n * tile, sm.B1);
   STAMP(13);
 
   // ---- dX_hat = x_hat dSs ; dx = (dX_hat - x_hat s) / n_x ----
@@ -623,7 +675,7 @@ ppm_fused_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* _
   }
   __syncthreads();
   STAMP(14);
-  store_tile(dd.dx + (size_t)n * tile, sm.B0, tile);
+  OUT_TILE(dd.dx + (size_t)n * tile, sm.B0);
   STAMP(15);
 }
 
@@ -653,6 +705,7 @@ bool WFN(fused_supported)(const pixpro_problem& pb) {
   if (P > 64 || P < 1) return false;
   if (pb.C != 16 * NWAVES && !(NWAVES == 8 && pb.C == 256)) return false;
   if ((size_t)pb.C * P > (size_t)PF * NTHREADS * 4) return false;
+  if (pb.layout == 1 && (NWAVES != 8 || P > 56)) return false;
   return smem_floats(pb.C, P) * sizeof(float) <= 160 * 1024;
 }
 

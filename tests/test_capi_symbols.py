@@ -25,7 +25,7 @@ def test_header_symbols_exported_and_bound():
 
 def test_struct_layout_matches_header():
     from contrast import _native
-    assert ctypes.sizeof(_native.Problem) == 14 * 4
+    assert ctypes.sizeof(_native.Problem) == 15 * 4
     assert ctypes.sizeof(_native.Dir) == 11 * ctypes.sizeof(ctypes.c_void_p)
 
 

@@ -240,3 +240,22 @@ def test_rejects_cpu_and_bad_shapes(dev):
         regression_loss(q.to(dev), q.to(dev), c.to(dev)[:1], c.to(dev), 0.7)
     with pytest.raises(RuntimeError, match="mask given without flow"):
         ops.regression_loss_op(q.to(dev), q.to(dev), c.to(dev), c.to(dev), 0.7, None, torch.ones(2, 4, 4, dtype=torch.bool, device=dev))
+
+
+@pytest.mark.parametrize("shape", [(6, 256, 7, 7), (5, 128, 7, 7), (4, 256, 2, 2), (3, 256, 6, 9)])
+def test_channels_last_tiles_consumed_in_place(dev, shape):
+    """NHWC (torch channels_last) features go through the same LDS image: results are bit-identical to the NCHW
+    call and the gradients come back channels_last (no layout copies on either side)."""
+    from contrast import _native as nv
+    N, C, H, W = shape
+    P = _random_problem(dev, N, C, H, W, 48, 64, seed=99 + C + H)
+    a, ga = _run_hip(dev, P, want_pred=True)
+    Q = dict(P)
+    for key in ("x1", "v1", "x2", "v2", "k1", "k2"):
+        Q[key] = P[key].to(dev).contiguous(memory_format=torch.channels_last)
+        assert nv.is_nhwc(Q[key])
+    b, gb = _run_hip(dev, Q, want_pred=True)
+    assert torch.equal(a[1], b[1]) and a[0].item() == b[0].item()
+    assert torch.equal(a[4], b[4])
+    for u, v in zip(ga, gb):
+        assert nv.is_nhwc(v) and torch.equal(u, v)
