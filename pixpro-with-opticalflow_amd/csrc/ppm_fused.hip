@@ -440,7 +440,7 @@ ppm_fused_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* _
     for (int nn = 0; nn < NT; ++nn) Y[m][nn] = zero4;
   gemm_cp<MT, NT>(Y, KS,
                   [&](int m, int ks) {
-                    const int j = min(4 * ks + lq, P - 1);
+                    const int j = 4 * ks + lq;     // j >= P reads the next row / the zeroed pad: finite, times a zero B row
                     return sm.B1[arow(m) * P + j] * sm.rv[j];
                   },
                   [&](int nn, int ks) { return sm.AA[(4 * ks + lq) * LS + 16 * nn + lr]; });
@@ -495,15 +495,22 @@ ppm_fused_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* _
 #pragma unroll
     for (int nn = 0; nn < NT; ++nn) G[m][nn] = zero4;
   {
-    unsigned long long rowbits[NT];
+    // row bits pre-shifted by the lane's k offset: bit 4*ks of the low / high word is M[i][4*ks + lq]
+    unsigned lo[NT], hi[NT];
 #pragma unroll
-    for (int nn = 0; nn < NT; ++nn) rowbits[nn] = sm.mbits[16 * nn + lr] >> lq;
+    for (int nn = 0; nn < NT; ++nn) {
+      const unsigned long long rb = sm.mbits[16 * nn + lr] >> lq;
+      lo[nn] = (unsigned)rb; hi[nn] = (unsigned)(rb >> 32);
+    }
     gemm_cp<MT, NT>(G, KS,
                     [&](int m, int ks) {
-                      const int j = min(4 * ks + lq, P - 1);
+                      const int j = 4 * ks + lq;
                       return sm.B0[arow(m) * P + j] * sm.rk[j];
                     },
-                    [&](int nn, int ks) { return ((rowbits[nn] >> (4 * ks)) & 1ull) ? 1.f : 0.f; });
+                    [&](int nn, int ks) {
+                      const unsigned w = ks < 8 ? lo[nn] : hi[nn];
+                      return (float)((w >> ((4 * ks) & 31)) & 1u);
+                    });
   }
   STAMP(7);
   float tc[NT];      // <Y_hat[:, i], G[:, i]> of this lane's columns
@@ -594,7 +601,7 @@ ppm_fused_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* _
 #pragma unroll
       for (int nn = 0; nn < NT; ++nn) T[m][nn] = zero4;
     gemm_cp<MT, NT>(T, KS,
-                    [&](int m, int ks) { return sm.B0[arow(m) * P + min(4 * ks + lq, P - 1)]; },
+                    [&](int m, int ks) { return sm.B0[arow(m) * P + 4 * ks + lq]; },
                     [&](int nn, int ks) { return sm.AA[(4 * ks + lq) * LS + 16 * nn + lr]; });
     float vh[MT][NT][4];
     float v[NT];
@@ -640,7 +647,7 @@ ppm_fused_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* _
       for (int nn = 0; nn < NT; ++nn) T[m][nn] = zero4;
     gemm_cp<MT, NT>(T, KS,
                     [&](int m, int ks) {
-                      const int j = min(4 * ks + lq, P - 1);
+                      const int j = 4 * ks + lq;
                       return sm.B0[arow(m) * P + j] * sm.rx[j];
                     },
                     [&](int nn, int ks) { return sm.Dm[(4 * ks + lq) * LS + 16 * nn + lr]; });
