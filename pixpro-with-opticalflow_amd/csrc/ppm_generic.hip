@@ -424,7 +424,10 @@ int run_featprop(const pixpro_problem& pb, const float* x, const float* v, const
     LAUNCH(k_copy_out, B * R, D, T, B, N, R);
     return PIXPRO_OK;
   }
-  hipMemcpyAsync(G, dY, B * R * sizeof(float), hipMemcpyDeviceToDevice, st);
+  if (hipMemcpyAsync(G, dY, B * R * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {
+    set_error("hipMemcpyAsync(dY) failed");
+    return PIXPRO_ERR_LAUNCH;
+  }
   APPLY(G, A, T, 1);
   LAUNCH(k_coldot, (size_t)B * P, vh, T, scol, B, C, P);
   LAUNCH(k_project, B * R, D, 1, nullptr, T, vh, scol, nv, B, N, C, P);
