@@ -23,22 +23,27 @@ __device__ __forceinline__ const float* src_of(const Dirs& D, int which, int d) 
 
 // dst[b,c,j] = src[b,c,j] / max(||src[b,:,j]||, 1e-12) (or a copy when do_norm == 0);
 // norm[b,j] = the clamped norm.  F.normalize(dim=1), PixPro.py:344,348,380,403.
-__global__ void k_normalize(Dirs D, int which, const float* __restrict__ ws_src, float* __restrict__ dst,
-                            float* __restrict__ norm, int B, int N, int C, int P, int do_norm) {
-  const size_t idx = (size_t)blockIdx.x * TPB + threadIdx.x;
-  if (idx >= (size_t)B * P) return;
-  const int b = (int)(idx / P), j = (int)(idx % P);
+// Block = 64 columns x 4 channel groups (coalesced 256-B rows), grid (ceil(P/64), B).
+__global__ void __launch_bounds__(TPB) k_normalize(Dirs D, int which, const float* __restrict__ ws_src,
+                                                   float* __restrict__ dst, float* __restrict__ norm, int B, int N,
+                                                   int C, int P, int do_norm) {
+  __shared__ float red[4][64];
+  const int b = blockIdx.y, tx = threadIdx.x & 63, ty = threadIdx.x >> 6, j = blockIdx.x * 64 + tx;
   const float* s = ws_src ? ws_src + (size_t)b * C * P : src_of(D, which, b / N) + (size_t)(b % N) * C * P;
   float* o = dst + (size_t)b * C * P;
   float nn = 1.f;
   if (do_norm) {
     float acc = 0.f;
-    for (int c = 0; c < C; ++c) { float t = s[(size_t)c * P + j]; acc += t * t; }
-    nn = fmaxf(sqrtf(acc), 1e-12f);
+    if (j < P)
+      for (int c = ty; c < C; c += 4) { const float t = s[(size_t)c * P + j]; acc = __builtin_fmaf(t, t, acc); }
+    red[ty][tx] = acc;
+    __syncthreads();
+    nn = fmaxf(sqrtf(red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx]), 1e-12f);
   }
-  if (norm) norm[idx] = nn;
-  for (int c = 0; c < C; ++c) {
-    float t = s[(size_t)c * P + j];
+  if (j >= P) return;
+  if (norm && ty == 0) norm[(size_t)b * P + j] = nn;
+  for (int c = ty; c < C; c += 4) {
+    const float t = s[(size_t)c * P + j];
     o[(size_t)c * P + j] = do_norm ? t / nn : t;
   }
 }
@@ -185,16 +190,18 @@ __global__ void k_count(const float* __restrict__ M, float* __restrict__ cnt, fl
 }
 
 // tcol[b,i] = sum_c A[b,c,i]*Bm[b,c,i]
-__global__ void k_coldot(const float* __restrict__ A, const float* __restrict__ Bm, float* __restrict__ tcol, int B,
-                         int C, int P) {
-  const size_t idx = (size_t)blockIdx.x * TPB + threadIdx.x;
-  if (idx >= (size_t)B * P) return;
-  const int b = (int)(idx / P), i = (int)(idx % P);
+__global__ void __launch_bounds__(TPB) k_coldot(const float* __restrict__ A, const float* __restrict__ Bm,
+                                                float* __restrict__ tcol, int B, int C, int P) {
+  __shared__ float red[4][64];
+  const int b = blockIdx.y, tx = threadIdx.x & 63, ty = threadIdx.x >> 6, i = blockIdx.x * 64 + tx;
   const float* a = A + (size_t)b * C * P;
   const float* bb = Bm + (size_t)b * C * P;
   float acc = 0.f;
-  for (int c = 0; c < C; ++c) acc = __builtin_fmaf(a[(size_t)c * P + i], bb[(size_t)c * P + i], acc);
-  tcol[idx] = acc;
+  if (i < P)
+    for (int c = ty; c < C; c += 4) acc = __builtin_fmaf(a[(size_t)c * P + i], bb[(size_t)c * P + i], acc);
+  red[ty][tx] = acc;
+  __syncthreads();
+  if (ty == 0 && i < P) tcol[(size_t)b * P + i] = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
 }
 
 // one block per b: loss_n[b] = sum_i tcol[b,i] / (cnt[b] + 1e-6)   (PixPro.py:241)
@@ -323,6 +330,11 @@ size_t generic_workspace_bytes(const pixpro_problem& pb) {
     hipLaunchKernelGGL(kern, dim3(blocks_for(n)), dim3(TPB), 0, st, __VA_ARGS__);      \
     if (int e = check_launch(#kern)) return e;                                        \
   } while (0)
+#define LAUNCH_G(kern, ...)                                                                    \
+  do {                                                                                         \
+    hipLaunchKernelGGL(kern, dim3((P + 63) / 64, B), dim3(TPB), 0, st, __VA_ARGS__);            \
+    if (int e = check_launch(#kern)) return e;                                                 \
+  } while (0)
 #define LAUNCH_B(kern, nb, ...)                                                       \
   do {                                                                                \
     hipLaunchKernelGGL(kern, dim3(nb), dim3(TPB), 0, st, __VA_ARGS__);                 \
@@ -355,13 +367,13 @@ int run_generic(const pixpro_problem& pb, const pixpro_dir* dirs, float* loss_n,
   LAUNCH(k_points, (size_t)B * P, pb, D, pts, diag, B);
   LAUNCH(k_mask, B * Q, pts, diag, M, B, P, pb.pos_ratio);
   LAUNCH_B(k_count, B, M, cnt, pos_num, pos_mean, P);
-  LAUNCH(k_normalize, (size_t)B * P, D, SRC_K, nullptr, kh, nullptr, B, N, C, P, mode == 0 ? pb.normalize_k : 0);
+  LAUNCH_G(k_normalize, D, SRC_K, nullptr, kh, nullptr, B, N, C, P, mode == 0 ? pb.normalize_k : 0);
 
   if (mode == 1) {
     // q is given: loss_n = <q, K M^T>/den ; dq = g0/den * K M^T
-    LAUNCH(k_normalize, (size_t)B * P, D, SRC_X, nullptr, Yh, nullptr, B, N, C, P, 0);
+    LAUNCH_G(k_normalize, D, SRC_X, nullptr, Yh, nullptr, B, N, C, P, 0);
     APPLY(kh, M, G, 0);
-    LAUNCH(k_coldot, (size_t)B * P, Yh, G, tcol, B, C, P);
+    LAUNCH_G(k_coldot, Yh, G, tcol, B, C, P);
     LAUNCH_B(k_loss_n, B, tcol, cnt, loss_n, P);
     LAUNCH_B(k_finalize, 1, loss_n, loss, B, N);
     if (want_grad) LAUNCH(k_scale_dq, B * R, D, G, cnt, B, N, R, g0);
@@ -369,28 +381,28 @@ int run_generic(const pixpro_problem& pb, const pixpro_dir* dirs, float* loss_n,
   }
 
   // forward: PPM
-  LAUNCH(k_normalize, (size_t)B * P, D, SRC_X, nullptr, xh, nx, B, N, C, P, 1);
-  LAUNCH(k_normalize, (size_t)B * P, D, SRC_V, nullptr, vh, nv, B, N, C, P, 1);
+  LAUNCH_G(k_normalize, D, SRC_X, nullptr, xh, nx, B, N, C, P, 1);
+  LAUNCH_G(k_normalize, D, SRC_V, nullptr, vh, nv, B, N, C, P, 1);
   GRAM(xh, xh, dS);                     // S (in dS buffer)
   LAUNCH(k_powmap, B * Q, dS, A, Dm, B * Q, pb.p, pb.clamp);
   APPLY(vh, A, T, 0);                   // Y = vh * A^T
-  LAUNCH(k_normalize, (size_t)B * P, D, SRC_X, T, Yh, ny, B, N, C, P, 1);  // Yh, ny
+  LAUNCH_G(k_normalize, D, SRC_X, T, Yh, ny, B, N, C, P, 1);  // Yh, ny
   LAUNCH(k_copy_out, B * R, D, Yh, B, N, R);
   // loss
   APPLY(kh, M, G, 0);                   // G = kh * M^T
-  LAUNCH(k_coldot, (size_t)B * P, Yh, G, tcol, B, C, P);
+  LAUNCH_G(k_coldot, Yh, G, tcol, B, C, P);
   LAUNCH_B(k_loss_n, B, tcol, cnt, loss_n, P);
   LAUNCH_B(k_finalize, 1, loss_n, loss, B, N);
   if (!want_grad) return PIXPRO_OK;
   // backward
   LAUNCH(k_dy, B * R, G, Yh, tcol, ny, cnt, B, C, P, g0);         // G <- dY
   APPLY(G, A, T, 1);                    // dVh = dY * A
-  LAUNCH(k_coldot, (size_t)B * P, vh, T, scol, B, C, P);
+  LAUNCH_G(k_coldot, vh, T, scol, B, C, P);
   LAUNCH(k_project, B * R, D, 1, nullptr, T, vh, scol, nv, B, N, C, P);   // dv
   GRAM(G, vh, M);                       // dA (in M buffer)
   LAUNCH(k_symm, B * Q, M, Dm, dS, B, P);
   APPLY(xh, dS, T, 1);                  // dXh = xh * dSs
-  LAUNCH(k_coldot, (size_t)B * P, xh, T, scol, B, C, P);
+  LAUNCH_G(k_coldot, xh, T, scol, B, C, P);
   LAUNCH(k_project, B * R, D, 0, nullptr, T, xh, scol, nx, B, N, C, P);   // dx
   return PIXPRO_OK;
 }
@@ -415,8 +427,8 @@ int run_featprop(const pixpro_problem& pb, const float* x, const float* v, const
         *scol = w.f((size_t)B * P);
   float *A = w.f(B * Q), *Dm = w.f(B * Q), *M = w.f(B * Q), *dS = w.f(B * Q);
   (void)kh; (void)Yh; (void)ny; (void)tcol;
-  LAUNCH(k_normalize, (size_t)B * P, D, SRC_X, nullptr, xh, nx, B, N, C, P, 1);
-  LAUNCH(k_normalize, (size_t)B * P, D, SRC_V, nullptr, vh, nv, B, N, C, P, 1);
+  LAUNCH_G(k_normalize, D, SRC_X, nullptr, xh, nx, B, N, C, P, 1);
+  LAUNCH_G(k_normalize, D, SRC_V, nullptr, vh, nv, B, N, C, P, 1);
   GRAM(xh, xh, dS);
   LAUNCH(k_powmap, B * Q, dS, A, Dm, B * Q, pb.p, pb.clamp);
   if (!dY) {
@@ -429,12 +441,12 @@ int run_featprop(const pixpro_problem& pb, const float* x, const float* v, const
     return PIXPRO_ERR_LAUNCH;
   }
   APPLY(G, A, T, 1);
-  LAUNCH(k_coldot, (size_t)B * P, vh, T, scol, B, C, P);
+  LAUNCH_G(k_coldot, vh, T, scol, B, C, P);
   LAUNCH(k_project, B * R, D, 1, nullptr, T, vh, scol, nv, B, N, C, P);
   GRAM(G, vh, M);
   LAUNCH(k_symm, B * Q, M, Dm, dS, B, P);
   APPLY(xh, dS, T, 1);
-  LAUNCH(k_coldot, (size_t)B * P, xh, T, scol, B, C, P);
+  LAUNCH_G(k_coldot, xh, T, scol, B, C, P);
   LAUNCH(k_project, B * R, D, 0, nullptr, T, xh, scol, nx, B, N, C, P);
   return PIXPRO_OK;
 }
