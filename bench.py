@@ -157,6 +157,59 @@ def cpu_baseline(a, args):
             "flow_ms_per_image": round(t_flow * 1e3, 3), "ppm_ms_per_image": round(t_ppm * 1e3, 4)}
 
 
+def cpu_cfg1_step():
+    """BASELINE configs[0] on the host: ResNet-18, 64x64 2-frame crops + identity flow on a 320x180 frame, batch 8,
+    one process, no GPU.  The product has no CPU route, so - exactly as tests/test_dist_gloo.py does - the two HIP
+    entry points the step needs are substituted here by the oracle; everything else is the shipped host code."""
+    import importlib
+    import types
+    from oracle import pixpro_oracle as O
+    from contrast import ops, resnet
+    pixpro_mod = importlib.import_module("contrast.models.PixPro")
+
+    def oracle_ppm_loss(dirs, p, clamp, pos_ratio, normalize_k=True, want_pred=False, generic=False):
+        total, nums, means = 0, [], []
+        for d in dirs:
+            a_ = [d.coord_q, [d.flow, d.size, d.mask]] if d.flow is not None else d.coord_q
+            b_ = [d.coord_k, None] if d.flow is not None else d.coord_k
+            with O.aten_samplers():
+                loss, _, pn, pm = O.ppm_loss(d.x, d.v, d.k, a_, b_, p, clamp, pos_ratio, normalize_k)
+            total = total + loss
+            nums.append(pn)
+            means.append(pm)
+        return total, torch.stack(nums), torch.stack(means), None
+
+    def oracle_ema(pq, pk, m):
+        for q, k in zip(pq, pk):
+            k.data.mul_(m).add_(q.data, alpha=1. - m)
+
+    saved = (ops.ppm_loss, pixpro_mod.ema_update)
+    ops.ppm_loss, pixpro_mod.ema_update = oracle_ppm_loss, oracle_ema
+    try:
+        margs = types.SimpleNamespace(pixpro_p=2.0, pixpro_momentum=0.99, pixpro_pos_ratio=0.7, pixpro_clamp_value=0.0,
+                                      pixpro_transform_layer=1, pixpro_ins_loss_weight=0.0, output_dir="/tmp",
+                                      num_instances=70000, batch_size=8, epochs=2000, start_epoch=1, feature_dim=256,
+                                      head_type="early_return", sync_bn=False)
+        torch.manual_seed(0)
+        model = pixpro_mod.PixPro(resnet.resnet18, margs).train()
+        opt = torch.optim.SGD(model.parameters(), lr=0.03, momentum=0.9, weight_decay=1e-5)
+        from contrast.synthetic import make_batch
+        d = make_batch(8, image_size=64, n_frames=2, frame_hw=(180, 320), device="cpu", seed=7, with_flow=False)
+        zf = torch.zeros(8, 2, 180, 320)
+        c1, c2 = [d[2], [zf, (180, 320), None]], [d[3], [zf, (180, 320), None]]
+        ts = []
+        for i in range(4):
+            t0 = time.perf_counter()
+            loss, _ = model(d[0], d[1], c1, c2)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            ts.append(time.perf_counter() - t0)
+        return 8.0 / (sum(ts[1:]) / len(ts[1:]))
+    finally:
+        ops.ppm_loss, pixpro_mod.ema_update = saved
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -273,6 +326,12 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             note(rank, "timing the CPU oracle on a bounded sample")
             cb = cpu_baseline(a, args)
+            try:
+                cb["cfg1_whole_step_images_per_s"] = round(cpu_cfg1_step(), 2)
+                cb["cfg1_note"] = ("BASELINE configs[0]: ResNet-18, 64x64 crops, identity flow, batch 8, whole step on the "
+                                   "host cores (hot path = oracle, encoders = torch CPU)")
+            except Exception as exc:      # the baseline is informative; never fail the bench line for it
+                cb["cfg1_note"] = f"cfg1 CPU step not timed: {exc!r}"
             out["cpu_baseline"] = cb
             hot_ms = ms.get("flow_prepare", 0.0) + ms.get("ppm_loss", 0.0)
             out["hot_path_gpu"] = {"images_per_s": round(a.batch / (hot_ms * 1e-3), 1),
