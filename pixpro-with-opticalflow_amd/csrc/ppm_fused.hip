@@ -237,25 +237,46 @@ __device__ __forceinline__ void col_reduce_reg(float (&v)[NT], float* part) {
   }
 }
 
-// C x P contraction: acc[m][n] += sum_k Aop(m, k) * Bop(n, k), k in steps of 4 (8 MFMAs per step hide
-// the LDS latency of the next step's operands).
-template <int MT, int NT, class FA, class FB>
-__device__ __forceinline__ void gemm_cp(f32x4 (&acc)[MT][NT], int ksteps, FA fa, FB fb) {
+// C x P contraction: acc[m][n] += sum_k Aop(m, k) * Bop(n, k), k in steps of 4.  Software-pipelined by hand: the
+// operands of step k+1 are requested from LDS before the MFMAs of step k issue (hipcc otherwise places every ds_read
+// right in front of its consumer with an lgkmcnt(0) wait).
+template <int MT, int NT, class FA, class FS, class FB>
+__device__ __forceinline__ void gemm_cp(f32x4 (&acc)[MT][NT], int ksteps, FA fa, FS fs, FB fb) {
+  // fa(m, ks): raw A element, fs(ks): its per-column scale (applied when the MFMA issues, not when the data is
+  // requested), fb(n, ks): B element
+  float a[MT], b[NT], sc;
+#pragma unroll
+  for (int m = 0; m < MT; ++m) a[m] = fa(m, 0);
+#pragma unroll
+  for (int n = 0; n < NT; ++n) b[n] = fb(n, 0);
+  sc = fs(0);
   for (int ks = 0; ks < ksteps; ++ks) {
-    float a[MT], b[NT];
+    float an[MT], bn[NT], scn;
+    const int kn = ks + 1 < ksteps ? ks + 1 : ks;      // last step re-reads its own operands (never used)
 #pragma unroll
-    for (int m = 0; m < MT; ++m) a[m] = fa(m, ks);
+    for (int m = 0; m < MT; ++m) an[m] = fa(m, kn);
 #pragma unroll
-    for (int n = 0; n < NT; ++n) b[n] = fb(n, ks);
+    for (int n = 0; n < NT; ++n) bn[n] = fb(n, kn);
+    scn = fs(kn);
+    __builtin_amdgcn_sched_barrier(0);                 // keep the requests above ahead of the MFMAs below
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+    for (int m = 0; m < MT; ++m) {
+      const float am = a[m] * sc;
 #pragma unroll
-      for (int n = 0; n < NT; ++n) acc[m][n] = mfma16(a[m], b[n], acc[m][n]);
+      for (int n = 0; n < NT; ++n) acc[m][n] = mfma16(am, b[n], acc[m][n]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) a[m] = an[m];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) b[n] = bn[n];
+    sc = scn;
   }
 }
 
-// P x P contraction over K = C for up to two output tiles per wave (tiles `wave` and `wave + 8` of the
-// NT x NT grid): out[i][j] = sum_c L[c][i] * R[c][j].  Operand loads are issued KU k-steps ahead.
+// P x P contraction over K = C for up to two output tiles per wave (tiles `wave` and `wave + NWAVES` of the
+// NT x NT grid): out[i][j] = sum_c L[c][i] * R[c][j].  Double-buffered: the operands of the next KU k-steps are
+// requested before the MFMAs of the current KU steps issue.
 template <int NT>
 __device__ __forceinline__ void gemm_pp(f32x4& acc0, f32x4& acc1, const float* __restrict__ L,
                                         const float* __restrict__ R, int C, int P) {
@@ -272,19 +293,34 @@ __device__ __forceinline__ void gemm_pp(f32x4& acc0, f32x4& acc1, const float* _
   const float* lc = L + lq * P + i1;
   const float* rd = R + lq * P + j1;
   const int step = 4 * P;
-  for (int k0 = 0; k0 < C / 4; k0 += KU) {
-    float a[KU], b[KU], c[KU], d[KU];
+  const int nblk = C / 4 / KU;
+  float a[KU], b[KU], c[KU], d[KU];
+#pragma unroll
+  for (int u = 0; u < KU; ++u) {
+    a[u] = la[u * step]; b[u] = rb[u * step];
+    if (has1) { c[u] = lc[u * step]; d[u] = rd[u * step]; }
+  }
+  for (int blk = 0; blk < nblk; ++blk) {
+    float an[KU], bn[KU], cn[KU], dn[KU];
+    const int adv = blk + 1 < nblk ? KU * step : 0;     // the last block re-reads itself (never used)
+    la += adv; rb += adv; lc += adv; rd += adv;
 #pragma unroll
     for (int u = 0; u < KU; ++u) {
-      a[u] = la[u * step]; b[u] = rb[u * step];
-      if (has1) { c[u] = lc[u * step]; d[u] = rd[u * step]; }
+      an[u] = la[u * step]; bn[u] = rb[u * step];
+      if (has1) { cn[u] = lc[u * step]; dn[u] = rd[u * step]; }
     }
+    __builtin_amdgcn_sched_barrier(0);                 // keep the requests above ahead of the MFMAs below
 #pragma unroll
     for (int u = 0; u < KU; ++u) {
       acc0 = mfma16(a[u], b[u], acc0);
       if (has1) acc1 = mfma16(c[u], d[u], acc1);
     }
-    la += KU * step; rb += KU * step; lc += KU * step; rd += KU * step;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+      a[u] = an[u]; b[u] = bn[u];
+      if (has1) { c[u] = cn[u]; d[u] = dn[u]; }
+    }
   }
 }
 
@@ -438,11 +474,10 @@ ppm_fused_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* _
   for (int m = 0; m < MT; ++m)
 #pragma unroll
     for (int nn = 0; nn < NT; ++nn) Y[m][nn] = zero4;
+  // k index j >= P reads the next row / the zeroed pad: finite, times a zero B row
   gemm_cp<MT, NT>(Y, KS,
-                  [&](int m, int ks) {
-                    const int j = 4 * ks + lq;     // j >= P reads the next row / the zeroed pad: finite, times a zero B row
-                    return sm.B1[arow(m) * P + j] * sm.rv[j];
-                  },
+                  [&](int m, int ks) { return sm.B1[arow(m) * P + 4 * ks + lq]; },
+                  [&](int ks) { return sm.rv[4 * ks + lq]; },
                   [&](int nn, int ks) { return sm.AA[(4 * ks + lq) * LS + 16 * nn + lr]; });
   STAMP(5);
   float ry[NT];      // 1 / ||Y[:, i]|| of this lane's columns
@@ -503,10 +538,8 @@ ppm_fused_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* _
       lo[nn] = (unsigned)rb; hi[nn] = (unsigned)(rb >> 32);
     }
     gemm_cp<MT, NT>(G, KS,
-                    [&](int m, int ks) {
-                      const int j = 4 * ks + lq;
-                      return sm.B0[arow(m) * P + j] * sm.rk[j];
-                    },
+                    [&](int m, int ks) { return sm.B0[arow(m) * P + 4 * ks + lq]; },
+                    [&](int ks) { return sm.rk[4 * ks + lq]; },
                     [&](int nn, int ks) {
                       const unsigned w = ks < 8 ? lo[nn] : hi[nn];
                       return (float)((w >> ((4 * ks) & 31)) & 1u);
@@ -602,6 +635,7 @@ ppm_fused_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* _
       for (int nn = 0; nn < NT; ++nn) T[m][nn] = zero4;
     gemm_cp<MT, NT>(T, KS,
                     [&](int m, int ks) { return sm.B0[arow(m) * P + 4 * ks + lq]; },
+                    [&](int) { return 1.f; },
                     [&](int nn, int ks) { return sm.AA[(4 * ks + lq) * LS + 16 * nn + lr]; });
     float vh[MT][NT][4];
     float v[NT];
@@ -646,10 +680,8 @@ ppm_fused_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* _
 #pragma unroll
       for (int nn = 0; nn < NT; ++nn) T[m][nn] = zero4;
     gemm_cp<MT, NT>(T, KS,
-                    [&](int m, int ks) {
-                      const int j = 4 * ks + lq;
-                      return sm.B0[arow(m) * P + j] * sm.rx[j];
-                    },
+                    [&](int m, int ks) { return sm.B0[arow(m) * P + 4 * ks + lq]; },
+                    [&](int ks) { return sm.rx[4 * ks + lq]; },
                     [&](int nn, int ks) { return sm.Dm[(4 * ks + lq) * LS + 16 * nn + lr]; });
     float xh[MT][NT][4];
     float v[NT];
