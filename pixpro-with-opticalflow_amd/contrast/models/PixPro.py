@@ -72,6 +72,8 @@ def _unpack(coord_q, coord_k):
             flow, size, mask = flow
             if isinstance(mask, list):
                 mask = mask[0]
+        if hasattr(flow, "lo_own"):        # util.LazyFlow carries its own mask definition
+            mask = None
     return coord_q, coord_k, flow, size, mask
 
 

@@ -35,7 +35,7 @@ class Direction:
     def __init__(self, x, v, k, coord_q, coord_k, flow=None, mask=None, size=None):
         self.x, self.v, self.k = x, v, k
         self.coord_q, self.coord_k = coord_q, coord_k
-        self.flow, self.mask, self.size = flow, mask, size
+        self.flow, self.mask, self.size = flow, mask, size       # flow may be a util.LazyFlow (then mask is ignored)
 
 
 def _problem(dirs, p, clamp, pos_ratio, normalize_k, grad_scale=1.0, allow_nhwc=False):
@@ -60,8 +60,21 @@ def _problem(dirs, p, clamp, pos_ratio, normalize_k, grad_scale=1.0, allow_nhwc=
         k = nv.dev_f32(d.k, "k", shape, nhwc)
         cq = nv.dev_f32(d.coord_q, "coord_q", (N, 10))
         ck = nv.dev_f32(d.coord_k, "coord_k", (N, 10))
-        flow = mask = None
-        if d.flow is not None:
+        flow = mask = lo_own = lo_opp = None
+        if d.flow is not None and hasattr(d.flow, "lo_own"):          # util.LazyFlow: evaluated inside the kernel
+            lz = d.flow
+            lo_own = nv.dev_f32(lz.lo_own, "lo_own")
+            lo_opp = nv.dev_f32(lz.lo_opp, "lo_opp", lo_own.shape)
+            if lo_own.dim() != 5 or lo_own.shape[0] != N or lo_own.shape[1] != 1 or lo_own.shape[2] != 2:
+                raise RuntimeError(f"lazy flow: expected low-res maps [N,1,2,h,w] with N={N}, got {tuple(lo_own.shape)}")
+            lh, lw = int(lo_own.shape[-2]), int(lo_own.shape[-1])
+            if i and (lh, lw) != (pb.lo_h, pb.lo_w):
+                raise RuntimeError("both directions must use the same low-res flow size")
+            pb.lo_h, pb.lo_w = lh, lw
+            pb.lazy_mask = int(lz.with_mask)
+            pb.alpha1 = float(lz.alpha1) if lz.with_mask else 0.0
+            pb.alpha2 = float(lz.alpha2) if lz.with_mask else 0.0
+        elif d.flow is not None:
             if d.flow.dim() != 4 or d.flow.shape[0] != N or d.flow.shape[1] != 2:
                 raise RuntimeError(f"flow: expected [N,2,Hf,Wf] with N={N}, got {tuple(d.flow.shape)}")
             flow = nv.dev_f32(d.flow, "flow")
@@ -73,15 +86,18 @@ def _problem(dirs, p, clamp, pos_ratio, normalize_k, grad_scale=1.0, allow_nhwc=
                 mask = nv.dev_mask(d.mask, "mask", (N, Hf, Wf))
         elif d.mask is not None:
             raise RuntimeError("mask given without flow")
+        if lo_own is not None and d.size is None:
+            raise RuntimeError("lazy flow needs the frame size")
         Ho, Wo, size_dev = _size_fields(d.size, flow, x.device)
         if i and (Ho, Wo) != (pb.Ho, pb.Wo):
             raise RuntimeError("both directions must use the same frame size")
         pb.Ho, pb.Wo = Ho, Wo
-        keep += [x, v, k, cq, ck, flow, mask, size_dev]
+        keep += [x, v, k, cq, ck, flow, mask, size_dev, lo_own, lo_opp]
         c = cds[i]
         c.x, c.v, c.k = nv.ptr(x), nv.ptr(v), nv.ptr(k)
         c.coord_q, c.coord_k = nv.ptr(cq), nv.ptr(ck)
         c.flow, c.mask, c.size_dev = nv.ptr(flow), nv.ptr(mask), nv.ptr(size_dev)
+        c.lo_own, c.lo_opp = nv.ptr(lo_own), nv.ptr(lo_opp)
     return pb, cds, keep
 
 

@@ -124,6 +124,8 @@ def forward_backward_consistency(flow_fwd, flow_bwd, coords0=None, alpha_1=0.01,
 def calc_mask_ratio(mask):
     if mask is None:
         return None
+    if isinstance(mask, LazyMask):          # logging only: materialise with the dense kernel
+        mask = mask.dense()
     if isinstance(mask, MaskWithCounts):
         return mask.invalid_ratio()
     m = nv.dev_mask(mask, "mask", mask.shape)
@@ -134,6 +136,45 @@ def calc_mask_ratio(mask):
     out = torch.empty(n, dtype=torch.float32, device=m.device)
     nv.call("pixpro_mask_ratio", nv.ptr(m), nv.ptr(out), n, m.shape[-2] * m.shape[-1], nv.stream())
     return out.reshape(lead)
+
+
+class LazyFlow:
+    """Composed flow of one direction that has NOT been materialised (nframe = 2, --flow_up, --lazy-flow): it carries
+    the loader's 1/8-resolution maps of this and of the opposite direction plus alpha1 / alpha2, and the fused loss
+    kernel evaluates flow and consistency mask at its P sample points only.  `.dense()` materialises
+    (flow[N,2,Hf,Wf], mask[N,Hf,Wf] or None) with the dense kernel when something else needs the tensors."""
+
+    def __init__(self, lo_own, lo_opp, alpha1, alpha2):
+        self.lo_own, self.lo_opp = lo_own, lo_opp
+        self.alpha1, self.alpha2 = alpha1, alpha2
+        self._dense = None
+
+    @property
+    def with_mask(self):
+        return self.alpha1 is not None and self.alpha2 is not None
+
+    @property
+    def map_size(self):
+        return 8 * int(self.lo_own.shape[-2]), 8 * int(self.lo_own.shape[-1])
+
+    def dense(self):
+        if self._dense is None:
+            args = argparse.Namespace(use_flow_file=True, use_flow_frames=False, flow_cat_norm=False, flow_up=True,
+                                      alpha1=self.alpha1, alpha2=self.alpha2, lazy_flow=False, debug=False)
+            data = [None] * 5 + [[None, self.lo_own, self.lo_opp], [[None], [torch.tensor(2)]]]
+            fwd, _ = apply_optical_flow(data, None, args)
+            self._dense = (fwd[0], fwd[2])
+        return self._dense
+
+
+class LazyMask:
+    """Place-holder for the consistency mask of a LazyFlow (third element of the [flow, size, mask] triple)."""
+
+    def __init__(self, flow):
+        self.flow = flow
+
+    def dense(self):
+        return self.flow.dense()[1]
 
 
 class MaskWithCounts(torch.Tensor):
@@ -188,6 +229,12 @@ def apply_optical_flow(data, flow_model, args):
     lo_b = nv.dev_f32(lo_b, "flow_bwds", lo_f.shape)
     N, F1, two, h, w = lo_f.shape
     up = bool(args.flow_up)
+    if getattr(args, "lazy_flow", False) and F1 == 1 and up and not getattr(args, "debug", False):
+        # nothing is launched here: the loss kernel evaluates flow + mask at its sample points (ops.ppm_loss)
+        fwd = LazyFlow(lo_f, lo_b, args.alpha1, args.alpha2)
+        bwd = LazyFlow(lo_b, lo_f, args.alpha1, args.alpha2)
+        return ([fwd, size, LazyMask(fwd) if fwd.with_mask else None],
+                [bwd, size, LazyMask(bwd) if bwd.with_mask else None])
     Hf, Wf = (8 * h, 8 * w) if up else (h, w)
     dev = lo_f.device
     flow_fwd = torch.empty((N, 2, Hf, Wf), dtype=torch.float32, device=dev)

@@ -89,6 +89,12 @@ int validate_problem(const pixpro_problem* pb, const pixpro_dir* dirs, bool need
     if (q.flow && (pb->Hf < 1 || pb->Wf < 1)) return bad("flow given but Hf/Wf not set");
     if (q.mask && !q.flow) return bad("mask given without flow");
     if (q.flow && !q.size_dev && pb->Ho < 1) return bad("flow given without a frame size");
+    if ((q.lo_own == nullptr) != (q.lo_opp == nullptr)) return bad("lo_own and lo_opp go together");
+    if (q.lo_own) {
+      if (pb->lo_h < 2 || pb->lo_w < 2) return bad("lazy flow mode needs lo_h, lo_w >= 2");
+      if (q.flow || q.mask) return bad("lazy flow mode excludes dense flow / mask tensors");
+      if (!q.size_dev && pb->Ho < 1) return bad("lazy flow mode needs a frame size");
+    }
   }
   return PIXPRO_OK;
 }

@@ -213,6 +213,69 @@ __device__ __forceinline__ void displace_point(const float* __restrict__ flow_n,
   }
 }
 
+// forward_backward_consistency for ONE pixel (contrast/util.py:252-297).  (fx, fy): this direction's flow at the
+// pixel; `bwd` fetches the opposite flow (pixel units unless is_norm).  Returns validity; cycle flow in (cx, cy).
+template <class Fetch>
+__device__ __forceinline__ bool fbc_pixel(float fx, float fy, const Fetch& bwd, int Hf, int Wf, int y, int x,
+                                          float alpha1, float a2, int is_norm, float& cx, float& cy) {
+  const float wd1 = (float)(Wf - 1), ht1 = (float)(Hf - 1);
+  float fnx = fx, fny = fy;
+  if (!is_norm) { fnx = 2.f * fx / wd1; fny = 2.f * fy / ht1; }            // normalize_flow
+  const float c1x = (2.f * (float)x / wd1 - 1.f) + fnx;                     // util.py:276
+  const float c1y = (2.f * (float)y / ht1 - 1.f) + fny;
+  const bool inside = (fabsf(c1x) < 1.f) && (fabsf(c1y) < 1.f);             // :277
+  float bx, by;
+  if (is_norm) bilinear2(bwd, Hf, Wf, c1x, c1y, TapNone(), bx, by);
+  else bilinear2(bwd, Hf, Wf, c1x, c1y, TapNormFlow{wd1, ht1}, bx, by);     // :279
+  cx = fnx + bx; cy = fny + by;                                             // :280
+  const float cyc = cx * cx + cy * cy;                                      // :294
+  const float eps = alpha1 * ((fnx * fnx + fny * fny) + (bx * bx + by * by)) + a2;   // :295
+  return inside && ((cyc - eps) <= 0.f);                                    // :297
+}
+
+// alpha_2 / sqrt(h^2+w^2): torch.sqrt of an int64 tensor -> fp32, .item() -> double (util.py:290-292)
+__host__ __device__ inline float fbc_a2(double alpha2, int Hf, int Wf) {
+  const float diag = sqrtf((float)((int64_t)Hf * Hf + (int64_t)Wf * Wf));
+  return (float)(alpha2 / (double)diag);
+}
+
+// Lazy flow mode (nframe = 2, flow_up): add_optical_flow for one point with the composed flow (= upflow8 of the
+// low-res map, contrast/util.py:303-308) and the consistency mask evaluated ON DEMAND from the 1/8-resolution maps -
+// the same arithmetic, hence the same bits, as sampling the dense tensors k_prepare_up8 would have written.
+//   flow  : bilinear sample of up8(lo_own) at the point          (PixPro.py:64)
+//   valid : mask at the nearest pixel (PixPro.py:68-70) = forward_backward_consistency of that ONE pixel
+__device__ __forceinline__ void displace_point_lazy(const float* __restrict__ lo_own, const float* __restrict__ lo_opp,
+                                                    int h, int w, bool with_mask, float alpha1, double alpha2,
+                                                    const FlowGeom& g, float x, float y, float& ox, float& oy,
+                                                    bool& valid) {
+  const size_t hw = (size_t)h * w;
+  const FetchUp8 own{lo_own, lo_own + hw, h, w, up8_scale(h), up8_scale(w)};
+  const float gx = 2.f * (x / g.wo1) - 1.f;
+  const float gy = 2.f * (y / g.ho1) - 1.f;
+  float fx, fy;
+  bilinear2(own, g.Hf, g.Wf, gx, gy, TapNone(), fx, fy);
+  valid = true;
+  if (with_mask) {
+    const float ix = (gx + 1.f) * ((float)(g.Wf - 1) / 2.f);
+    const float iy = (gy + 1.f) * ((float)(g.Hf - 1) / 2.f);
+    const float xr = rintf(ix), yr = rintf(iy);
+    valid = false;
+    if (xr >= 0.f && xr < (float)g.Wf && yr >= 0.f && yr < (float)g.Hf) {
+      const FetchUp8 opp{lo_opp, lo_opp + hw, h, w, up8_scale(h), up8_scale(w)};
+      float px, py, cx, cy;
+      own((int)yr, (int)xr, px, py);
+      valid = fbc_pixel(px, py, opp, g.Hf, g.Wf, (int)yr, (int)xr, alpha1, fbc_a2(alpha2, g.Hf, g.Wf), 0, cx, cy);
+    }
+  }
+  if (g.diff) {
+    ox = (x * g.rw + fx) / g.rw;
+    oy = (y * g.rh + fy) / g.rh;
+  } else {
+    ox = x + fx;
+    oy = y + fy;
+  }
+}
+
 // Frame size for one problem: explicit device tensor, explicit ints, or coord_q[0][9], [0][8].
 __device__ __forceinline__ void frame_size(const pixpro_problem& pb, const pixpro_dir& d, int& Ho, int& Wo) {
   if (d.size_dev) { Ho = d.size_dev[0]; Wo = d.size_dev[1]; }

@@ -99,33 +99,7 @@ __global__ void k_chain(Source s0, Source s1, float* __restrict__ out0, float* _
   out[(size_t)n * 2 * HW + HW + r] = oy;
 }
 
-// ---- K7: forward_backward_consistency ----------------------------------------------------
-// (fx, fy): forward flow at the pixel; `bwd` fetches the backward flow (pixel units unless
-// is_norm).  Returns validity; cycle flow in (cx, cy).
-template <class Fetch>
-__device__ __forceinline__ bool fbc_pixel(float fx, float fy, const Fetch& bwd, int Hf, int Wf, int y, int x,
-                                          float alpha1, float a2, int is_norm, float& cx, float& cy) {
-  const float wd1 = (float)(Wf - 1), ht1 = (float)(Hf - 1);
-  float fnx = fx, fny = fy;
-  if (!is_norm) { fnx = 2.f * fx / wd1; fny = 2.f * fy / ht1; }            // normalize_flow
-  const float c1x = (2.f * (float)x / wd1 - 1.f) + fnx;                     // util.py:276
-  const float c1y = (2.f * (float)y / ht1 - 1.f) + fny;
-  const bool inside = (fabsf(c1x) < 1.f) && (fabsf(c1y) < 1.f);             // :277
-  float bx, by;
-  if (is_norm) bilinear2(bwd, Hf, Wf, c1x, c1y, TapNone(), bx, by);
-  else bilinear2(bwd, Hf, Wf, c1x, c1y, TapNormFlow{wd1, ht1}, bx, by);     // :279
-  cx = fnx + bx; cy = fny + by;                                             // :280
-  const float cyc = cx * cx + cy * cy;                                      // :294
-  const float eps = alpha1 * ((fnx * fnx + fny * fny) + (bx * bx + by * by)) + a2;   // :295
-  return inside && ((cyc - eps) <= 0.f);                                    // :297
-}
-
-// alpha_2 / sqrt(h^2+w^2): torch.sqrt of an int64 tensor -> fp32, .item() -> double (util.py:290-292)
-inline float fbc_a2(double alpha2, int Hf, int Wf) {
-  const float diag = sqrtf((float)((int64_t)Hf * Hf + (int64_t)Wf * Wf));
-  return (float)(alpha2 / (double)diag);
-}
-
+// ---- K7: forward_backward_consistency: fbc_pixel lives in common.h (shared with the lazy flow mode) ----
 __global__ void k_fbc(const float* __restrict__ f, const float* __restrict__ bw, uint8_t* __restrict__ mask,
                       float* __restrict__ cycle, int32_t* __restrict__ invalid, int N, int Hf, int Wf, float alpha1,
                       float a2, int is_norm) {

@@ -381,7 +381,14 @@ ppm_fused_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* _
       qx = centre_x(cq, col, wo1); qy = centre_y(cq, row, ho1);
       kx = centre_x(ck, col, wo1); ky = centre_y(ck, row, ho1);
       bool v = true;
-      if (dd.flow) {
+      if (dd.lo_own) {          // lazy flow mode: evaluate flow + validity at this point from the low-res maps
+        const FlowGeom fg = flow_geom(8 * pb.lo_h, 8 * pb.lo_w, Ho, Wo);
+        const size_t lo = (size_t)n * 2 * pb.lo_h * pb.lo_w;
+        float ox, oy;
+        displace_point_lazy(dd.lo_own + lo, dd.lo_opp + lo, pb.lo_h, pb.lo_w, pb.lazy_mask != 0, pb.alpha1, pb.alpha2,
+                            fg, qx, qy, ox, oy, v);
+        qx = ox; qy = oy;
+      } else if (dd.flow) {
         const FlowGeom fg = flow_geom(pb.Hf, pb.Wf, Ho, Wo);
         float ox, oy;
         displace_point(dd.flow + (size_t)n * 2 * pb.Hf * pb.Wf,

@@ -183,3 +183,31 @@ def test_public_featprop_and_instance_branch(dev):
     loss, pos = model(im, im, c, c)
     loss.backward()
     assert torch.isfinite(loss).item() and model.projector_instance.linear2.weight.grad is not None
+
+
+def test_train_step_lazy_flow_matches_dense(dev):
+    """main_pretrain.train_step with --lazy-flow gives the same loss / pos_num as the dense flow preparation."""
+    import main_pretrain
+    from contrast import option
+    from contrast.lr_scheduler import get_scheduler
+    from contrast.synthetic import make_batch
+    base = ["--model", "PixPro", "--arch", "resnet18", "--synthetic", "--use_flow", "--use_flow_file", "--flow_up",
+            "--alpha1", "0.01", "--alpha2", "0.5", "--n-frames", "2", "--optimizer", "sgd", "--base-lr", "0.1",
+            "--amp-opt-level", "O0", "--pixpro-p", "2", "--pixpro-transform-layer", "1", "--batch-size", "4",
+            "--epochs", "2", "--warmup-epoch", "0", "--head-type", "early_return"]
+    data = make_batch(4, image_size=64, n_frames=2, frame_hw=(96, 128), device=dev, sigma=0.8)
+    out = []
+    for extra in ([], ["--lazy-flow"]):
+        args = option.parse_option(argv=base + extra)
+        args.num_instances = 16
+        torch.manual_seed(0)
+        model, opt = main_pretrain.build_model(args, dev)
+        sched = get_scheduler(opt, 4, args)
+        model.train()
+        loss, pos, info = main_pretrain.train_step(model, opt, sched, data, args)
+        out.append((loss.item(), pos[0][0].clone(), pos[1][0].clone()))
+    # the hot path itself is bit-identical (test_lazy_flow_equals_dense); two separately built encoders are not
+    # (MIOpen fp32 convolutions re-associate from run to run), hence a tolerance on the loss
+    assert abs(out[0][0] - out[1][0]) <= 1e-5 * max(1.0, abs(out[0][0]))
+    assert torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][2], out[1][2])
+    assert out[0][1].sum() > 0

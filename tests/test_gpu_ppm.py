@@ -259,3 +259,51 @@ def test_channels_last_tiles_consumed_in_place(dev, shape):
     assert torch.equal(a[4], b[4])
     for u, v in zip(ga, gb):
         assert nv.is_nhwc(v) and torch.equal(u, v)
+
+
+@pytest.mark.parametrize("shape,frame,lo,sigma,masked", [
+    ((6, 256, 7, 7), (96, 128), (12, 16), 0.5, True), ((4, 256, 7, 7), (720, 1280), (90, 160), 0.5, True),
+    ((4, 256, 7, 7), (96, 128), (12, 16), 6.0, True), ((3, 128, 7, 7), (96, 128), (12, 16), 0.5, False),
+    ((2, 64, 14, 14), (96, 128), (12, 16), 1.0, True),            # staged path
+    ((4, 256, 7, 7), (192, 256), (12, 16), 0.5, True),            # flow map at half the frame size (ratio branch)
+])
+def test_lazy_flow_equals_dense(dev, shape, frame, lo, sigma, masked):
+    """--lazy-flow: flow + consistency mask evaluated inside the loss kernel at its P sample points from the 1/8-res
+    maps must reproduce the dense pipeline (apply_optical_flow -> dense tensors -> loss) bit for bit."""
+    import types
+    from contrast import ops, util
+    from recipes import crop_coords, smooth_flow
+    N, C, H, W = shape
+    gen = torch.Generator().manual_seed(31 + N + H)
+    rng = random.Random(5)
+    t = lambda: torch.randn(N, C, H, W, generator=gen).to(dev)
+    x1, v1, x2, v2, k1, k2 = t(), t(), t(), t(), t(), t()
+    c1 = crop_coords(N, frame[1], frame[0], rng).to(dev)
+    c2 = (c1 + 0.0).clone()
+    c2[:, :4] = (c1[:, :4] + 0.02 * torch.randn(N, 4, generator=gen).to(dev))
+    lo_f = smooth_flow((N, 1, 2, *lo), sigma, gen).to(dev)
+    lo_b = (-lo_f + smooth_flow((N, 1, 2, *lo), 0.1 * sigma, gen).to(dev)).contiguous()
+    size = torch.tensor(list(frame), device=dev)
+    data = [None] * 5 + [[None, lo_f, lo_b], [size.repeat(N, 1), torch.full((N, 1), 2, device=dev)]]
+    a1, a2 = (0.01, 0.5) if masked else (None, None)
+    base = dict(use_flow_file=True, use_flow_frames=False, flow_cat_norm=False, flow_up=True, alpha1=a1, alpha2=a2, debug=False)
+    dense_f, dense_b = util.apply_optical_flow(data, None, types.SimpleNamespace(lazy_flow=False, **base))
+    lazy_f, lazy_b = util.apply_optical_flow(data, None, types.SimpleNamespace(lazy_flow=True, **base))
+    assert isinstance(lazy_f[0], util.LazyFlow) and (lazy_f[2] is None) == (not masked)
+
+    def run(ff, fb):
+        xs = [z.clone().requires_grad_(True) for z in (x1, v1, x2, v2)]
+        d1 = ops.Direction(xs[0], xs[1], k2, c1, c2, ff[0], ff[2] if not isinstance(ff[0], util.LazyFlow) else None, ff[1])
+        d2 = ops.Direction(xs[2], xs[3], k1, c2, c1, fb[0], fb[2] if not isinstance(fb[0], util.LazyFlow) else None, fb[1])
+        out = ops.ppm_loss([d1, d2], 2.0, 0.0, 0.7, True)
+        out[0].backward()
+        return out, [z.grad for z in xs]
+
+    od, gd = run(dense_f, dense_b)
+    ol, gl = run(lazy_f, lazy_b)
+    assert torch.equal(od[1], ol[1]) and od[0].item() == ol[0].item()
+    assert od[1].sum() > 0
+    for u, v in zip(gd, gl):
+        assert torch.equal(u, v)
+    if masked:   # logging path: the lazy mask materialises to the same ratio as the dense one
+        assert torch.equal(util.calc_mask_ratio(lazy_f[2]), util.calc_mask_ratio(dense_f[2]))
