@@ -55,7 +55,7 @@ def parse():
     ap.add_argument("--n-frames", type=int, default=2)
     ap.add_argument("--arch", default="resnet50")
     ap.add_argument("--lazy-flow", action="store_true",
-                    help="nframe=2 only: skip the dense flow preparation, evaluate flow + mask inside the loss kernel "
+                    help="skip the dense flow preparation, evaluate flow chain + mask inside the loss kernel "
                          "(same results; the default keeps the reference's dense pipeline, which BASELINE's metric names)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-flow-images", type=int, default=8)

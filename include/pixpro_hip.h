@@ -50,14 +50,16 @@ typedef struct pixpro_problem {
   float grad_scale; /* upstream d(loss): grads are those of grad_scale * loss (normally 1) */
   int32_t layout;   /* memory order of x, v, k, pred, dx, dv: 0 = [N,C,P] (NCHW-contiguous), 1 = [N,P,C] (NHWC, i.e.
                        torch channels_last).  1 is accepted by pixpro_ppm_loss on the single-launch path only. */
-  /* Lazy flow mode (nframe = 2 with --flow_up): lo_h > 0 means the composed flow [N,2,8*lo_h,8*lo_w] and the
-   * consistency mask are NOT passed as dense tensors (pixpro_dir.flow / .mask are NULL); they are evaluated inside
-   * the kernel, at the P sample points only, from the loader's 1/8-resolution maps pixpro_dir.lo_own / .lo_opp
-   * ([N,1,2,lo_h,lo_w]) with the arithmetic of util.apply_optical_flow (util.py:174-248) - identical results,
-   * ~10^3 x fewer bytes than preparing the dense tensors.  lazy_mask = 0 reproduces alpha1/alpha2 = None. */
+  /* Lazy flow mode (--flow_up): lo_h > 0 means the composed flow [N,2,8*lo_h,8*lo_w] and the consistency mask are
+   * NOT passed as dense tensors (pixpro_dir.flow / .mask are NULL); they are evaluated inside the kernel, at the P
+   * sample points only, from the loader's 1/8-resolution stacks pixpro_dir.lo_own / .lo_opp
+   * ([N,lo_frames,2,lo_h,lo_w], lo_frames = nframe-1 flows chained as concat_flow does) with the arithmetic of
+   * util.apply_optical_flow (util.py:174-248) - identical results, ~10^3 x fewer bytes than preparing the dense
+   * tensors.  lazy_mask = 0 reproduces alpha1/alpha2 = None. */
   int32_t lo_h, lo_w;
   int32_t lazy_mask;
   float alpha1;
+  int32_t lo_frames;  /* flows per chain (nframe-1); 0 is read as 1 */
   double alpha2;
 } pixpro_problem;
 
@@ -75,8 +77,8 @@ typedef struct pixpro_dir {
   const float* flow;
   const uint8_t* mask;
   const int32_t* size_dev;
-  const float* lo_own;    /* lazy flow mode: low-res flow of this direction, [N,1,2,lo_h,lo_w] */
-  const float* lo_opp;    /* lazy flow mode: low-res flow of the opposite direction (for the mask) */
+  const float* lo_own;    /* lazy flow mode: low-res flows of this direction, [N,lo_frames,2,lo_h,lo_w] */
+  const float* lo_opp;    /* lazy flow mode: low-res flows of the opposite direction (for the mask) */
   float* pred;
   float* dx;
   float* dv;

@@ -24,7 +24,8 @@ class Problem(ctypes.Structure):
     _fields_ = [("N", _i32), ("C", _i32), ("H", _i32), ("W", _i32), ("Hf", _i32), ("Wf", _i32),
                 ("Ho", _i32), ("Wo", _i32), ("p", _f32), ("clamp", _f32), ("pos_ratio", _f32),
                 ("normalize_k", _i32), ("ndir", _i32), ("grad_scale", _f32), ("layout", _i32),
-                ("lo_h", _i32), ("lo_w", _i32), ("lazy_mask", _i32), ("alpha1", _f32), ("alpha2", _f64)]
+                ("lo_h", _i32), ("lo_w", _i32), ("lazy_mask", _i32), ("alpha1", _f32), ("lo_frames", _i32),
+                ("alpha2", _f64)]
 
 
 class Dir(ctypes.Structure):

@@ -65,12 +65,12 @@ def _problem(dirs, p, clamp, pos_ratio, normalize_k, grad_scale=1.0, allow_nhwc=
             lz = d.flow
             lo_own = nv.dev_f32(lz.lo_own, "lo_own")
             lo_opp = nv.dev_f32(lz.lo_opp, "lo_opp", lo_own.shape)
-            if lo_own.dim() != 5 or lo_own.shape[0] != N or lo_own.shape[1] != 1 or lo_own.shape[2] != 2:
-                raise RuntimeError(f"lazy flow: expected low-res maps [N,1,2,h,w] with N={N}, got {tuple(lo_own.shape)}")
-            lh, lw = int(lo_own.shape[-2]), int(lo_own.shape[-1])
-            if i and (lh, lw) != (pb.lo_h, pb.lo_w):
-                raise RuntimeError("both directions must use the same low-res flow size")
-            pb.lo_h, pb.lo_w = lh, lw
+            if lo_own.dim() != 5 or lo_own.shape[0] != N or lo_own.shape[1] < 1 or lo_own.shape[2] != 2:
+                raise RuntimeError(f"lazy flow: expected low-res maps [N,F-1,2,h,w] with N={N}, got {tuple(lo_own.shape)}")
+            lf, lh, lw = int(lo_own.shape[1]), int(lo_own.shape[-2]), int(lo_own.shape[-1])
+            if i and (lf, lh, lw) != (pb.lo_frames, pb.lo_h, pb.lo_w):
+                raise RuntimeError("both directions must use the same low-res flow stack shape")
+            pb.lo_frames, pb.lo_h, pb.lo_w = lf, lh, lw
             pb.lazy_mask = int(lz.with_mask)
             pb.alpha1 = float(lz.alpha1) if lz.with_mask else 0.0
             pb.alpha2 = float(lz.alpha2) if lz.with_mask else 0.0

@@ -82,7 +82,7 @@ _FLAGS = [
     (("--num-instances",), dict(type=int, default=70000, help="dataset length used for the EMA schedule with --synthetic")),
     (("--frame-size",), dict(nargs=2, type=int, default=[720, 1280], help="synthetic original frame (H W)")),
     (("--no-sync-bn",), dict(action="store_true")),
-    (("--lazy-flow",), dict(action="store_true", help="nframe=2: evaluate flow + consistency mask inside the loss kernel at "
+    (("--lazy-flow",), dict(action="store_true", help="evaluate flow chain + consistency mask inside the loss kernel at "
                                                       "its sample points instead of preparing dense tensors (same results)")),
     (("--channels-last",), dict(action="store_true")),
 ]

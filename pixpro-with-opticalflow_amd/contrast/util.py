@@ -139,8 +139,8 @@ def calc_mask_ratio(mask):
 
 
 class LazyFlow:
-    """Composed flow of one direction that has NOT been materialised (nframe = 2, --flow_up, --lazy-flow): it carries
-    the loader's 1/8-resolution maps of this and of the opposite direction plus alpha1 / alpha2, and the fused loss
+    """Composed flow of one direction that has NOT been materialised (--flow_up, --lazy-flow): it carries the
+    loader's 1/8-resolution stacks [N,F-1,2,h,w] of this and of the opposite direction plus alpha1 / alpha2, and the loss
     kernel evaluates flow and consistency mask at its P sample points only.  `.dense()` materialises
     (flow[N,2,Hf,Wf], mask[N,Hf,Wf] or None) with the dense kernel when something else needs the tensors."""
 
@@ -161,7 +161,7 @@ class LazyFlow:
         if self._dense is None:
             args = argparse.Namespace(use_flow_file=True, use_flow_frames=False, flow_cat_norm=False, flow_up=True,
                                       alpha1=self.alpha1, alpha2=self.alpha2, lazy_flow=False, debug=False)
-            data = [None] * 5 + [[None, self.lo_own, self.lo_opp], [[None], [torch.tensor(2)]]]
+            data = [None] * 5 + [[None, self.lo_own, self.lo_opp], [[None], [torch.tensor(self.lo_own.shape[1] + 1)]]]
             fwd, _ = apply_optical_flow(data, None, args)
             self._dense = (fwd[0], fwd[2])
         return self._dense
@@ -229,7 +229,7 @@ def apply_optical_flow(data, flow_model, args):
     lo_b = nv.dev_f32(lo_b, "flow_bwds", lo_f.shape)
     N, F1, two, h, w = lo_f.shape
     up = bool(args.flow_up)
-    if getattr(args, "lazy_flow", False) and F1 == 1 and up and not getattr(args, "debug", False):
+    if getattr(args, "lazy_flow", False) and up and not getattr(args, "debug", False):
         # nothing is launched here: the loss kernel evaluates flow + mask at its sample points (ops.ppm_loss)
         fwd = LazyFlow(lo_f, lo_b, args.alpha1, args.alpha2)
         bwd = LazyFlow(lo_b, lo_f, args.alpha1, args.alpha2)

@@ -92,6 +92,7 @@ int validate_problem(const pixpro_problem* pb, const pixpro_dir* dirs, bool need
     if ((q.lo_own == nullptr) != (q.lo_opp == nullptr)) return bad("lo_own and lo_opp go together");
     if (q.lo_own) {
       if (pb->lo_h < 2 || pb->lo_w < 2) return bad("lazy flow mode needs lo_h, lo_w >= 2");
+      if (pb->lo_frames < 0 || pb->lo_frames > 64) return bad("lazy flow mode: lo_frames must be in 0..64");
       if (q.flow || q.mask) return bad("lazy flow mode excludes dense flow / mask tensors");
       if (!q.size_dev && pb->Ho < 1) return bad("lazy flow mode needs a frame size");
     }

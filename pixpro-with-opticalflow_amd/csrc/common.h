@@ -145,27 +145,44 @@ struct FetchUp8 {
   }
 };
 
-template <class Fetch, class Tap>
-__device__ __forceinline__ void bilinear2(const Fetch& fetch, int Hf, int Wf, float gx, float gy, const Tap& tap,
-                                          float& ox, float& oy) {
+// Geometry of one bilinear sample: corner pixel, the four weights and which taps lie inside the map
+// (bit k: tap k of (y0,x0), (y0,x1), (y1,x0), (y1,x1)); taps outside contribute zero (padding_mode='zeros').
+struct BilinGeom {
+  int x0, y0, in;
+  float nw, ne, sw, se;
+};
+__device__ __forceinline__ BilinGeom bilin_geom(int Hf, int Wf, float gx, float gy) {
+  BilinGeom b;
   const float ix = (gx + 1.f) * ((float)(Wf - 1) / 2.f);
   const float iy = (gy + 1.f) * ((float)(Hf - 1) / 2.f);
   const float xw = floorf(ix), yn = floorf(iy);
   const float w = ix - xw, e = 1.f - w, n = iy - yn, s = 1.f - n;
-  const float nw = s * e, ne = s * w, sw = n * e, se = n * w;
+  b.nw = s * e; b.ne = s * w; b.sw = n * e; b.se = n * w;
   // float -> int keeping far-away (or NaN) coordinates out of range
-  const int x0 = (xw > -2.f && xw < (float)(Wf + 1)) ? (int)xw : -2;
-  const int y0 = (yn > -2.f && yn < (float)(Hf + 1)) ? (int)yn : -2;
-  const int x1 = x0 + 1, y1 = y0 + 1;
-  const bool bx0 = x0 >= 0 && x0 < Wf, bx1 = x1 >= 0 && x1 < Wf;
-  const bool by0 = y0 >= 0 && y0 < Hf, by1 = y1 >= 0 && y1 < Hf;
+  b.x0 = (xw > -2.f && xw < (float)(Wf + 1)) ? (int)xw : -2;
+  b.y0 = (yn > -2.f && yn < (float)(Hf + 1)) ? (int)yn : -2;
+  const int x1 = b.x0 + 1, y1 = b.y0 + 1;
+  const bool bx0 = b.x0 >= 0 && b.x0 < Wf, bx1 = x1 >= 0 && x1 < Wf;
+  const bool by0 = b.y0 >= 0 && b.y0 < Hf, by1 = y1 >= 0 && y1 < Hf;
+  b.in = (by0 && bx0 ? 1 : 0) | (by0 && bx1 ? 2 : 0) | (by1 && bx0 ? 4 : 0) | (by1 && bx1 ? 8 : 0);
+  return b;
+}
+__device__ __forceinline__ float bilin_combine(const BilinGeom& b, float v0, float v1, float v2, float v3) {
+  return __builtin_fmaf(v3, b.se, __builtin_fmaf(v2, b.sw, __builtin_fmaf(v1, b.ne, v0 * b.nw)));
+}
+
+template <class Fetch, class Tap>
+__device__ __forceinline__ void bilinear2(const Fetch& fetch, int Hf, int Wf, float gx, float gy, const Tap& tap,
+                                          float& ox, float& oy) {
+  const BilinGeom b = bilin_geom(Hf, Wf, gx, gy);
+  const int x1 = b.x0 + 1, y1 = b.y0 + 1;
   float ax = 0.f, ay = 0.f, bxv = 0.f, byv = 0.f, cxv = 0.f, cyv = 0.f, dxv = 0.f, dyv = 0.f;
-  if (by0 && bx0) { fetch(y0, x0, ax, ay); ax = tap.x(ax); ay = tap.y(ay); }
-  if (by0 && bx1) { fetch(y0, x1, bxv, byv); bxv = tap.x(bxv); byv = tap.y(byv); }
-  if (by1 && bx0) { fetch(y1, x0, cxv, cyv); cxv = tap.x(cxv); cyv = tap.y(cyv); }
-  if (by1 && bx1) { fetch(y1, x1, dxv, dyv); dxv = tap.x(dxv); dyv = tap.y(dyv); }
-  ox = __builtin_fmaf(dxv, se, __builtin_fmaf(cxv, sw, __builtin_fmaf(bxv, ne, ax * nw)));
-  oy = __builtin_fmaf(dyv, se, __builtin_fmaf(cyv, sw, __builtin_fmaf(byv, ne, ay * nw)));
+  if (b.in & 1) { fetch(b.y0, b.x0, ax, ay); ax = tap.x(ax); ay = tap.y(ay); }
+  if (b.in & 2) { fetch(b.y0, x1, bxv, byv); bxv = tap.x(bxv); byv = tap.y(byv); }
+  if (b.in & 4) { fetch(y1, b.x0, cxv, cyv); cxv = tap.x(cxv); cyv = tap.y(cyv); }
+  if (b.in & 8) { fetch(y1, x1, dxv, dyv); dxv = tap.x(dxv); dyv = tap.y(dyv); }
+  ox = bilin_combine(b, ax, bxv, cxv, dxv);
+  oy = bilin_combine(b, ay, byv, cyv, dyv);
 }
 
 // grid_sample(nearest, zeros, align_corners=True) of a uint8 mask -> bool (PixPro.py:68-70)
@@ -215,22 +232,36 @@ __device__ __forceinline__ void displace_point(const float* __restrict__ flow_n,
 
 // forward_backward_consistency for ONE pixel (contrast/util.py:252-297).  (fx, fy): this direction's flow at the
 // pixel; `bwd` fetches the opposite flow (pixel units unless is_norm).  Returns validity; cycle flow in (cx, cy).
+struct FbcHead {
+  float fnx, fny, c1x, c1y;
+  bool inside;
+};
+__device__ __forceinline__ FbcHead fbc_head(float fx, float fy, int Hf, int Wf, int y, int x, int is_norm) {
+  const float wd1 = (float)(Wf - 1), ht1 = (float)(Hf - 1);
+  FbcHead h;
+  h.fnx = fx; h.fny = fy;
+  if (!is_norm) { h.fnx = 2.f * fx / wd1; h.fny = 2.f * fy / ht1; }        // normalize_flow
+  h.c1x = (2.f * (float)x / wd1 - 1.f) + h.fnx;                             // util.py:276
+  h.c1y = (2.f * (float)y / ht1 - 1.f) + h.fny;
+  h.inside = (fabsf(h.c1x) < 1.f) && (fabsf(h.c1y) < 1.f);                  // :277
+  return h;
+}
+// (bx, by): the opposite flow, normalised, sampled at (c1x, c1y)                 // :279
+__device__ __forceinline__ bool fbc_tail(const FbcHead& h, float bx, float by, float alpha1, float a2, float& cx,
+                                         float& cy) {
+  cx = h.fnx + bx; cy = h.fny + by;                                         // :280
+  const float cyc = cx * cx + cy * cy;                                      // :294
+  const float eps = alpha1 * ((h.fnx * h.fnx + h.fny * h.fny) + (bx * bx + by * by)) + a2;   // :295
+  return h.inside && ((cyc - eps) <= 0.f);                                  // :297
+}
 template <class Fetch>
 __device__ __forceinline__ bool fbc_pixel(float fx, float fy, const Fetch& bwd, int Hf, int Wf, int y, int x,
                                           float alpha1, float a2, int is_norm, float& cx, float& cy) {
-  const float wd1 = (float)(Wf - 1), ht1 = (float)(Hf - 1);
-  float fnx = fx, fny = fy;
-  if (!is_norm) { fnx = 2.f * fx / wd1; fny = 2.f * fy / ht1; }            // normalize_flow
-  const float c1x = (2.f * (float)x / wd1 - 1.f) + fnx;                     // util.py:276
-  const float c1y = (2.f * (float)y / ht1 - 1.f) + fny;
-  const bool inside = (fabsf(c1x) < 1.f) && (fabsf(c1y) < 1.f);             // :277
+  const FbcHead h = fbc_head(fx, fy, Hf, Wf, y, x, is_norm);
   float bx, by;
-  if (is_norm) bilinear2(bwd, Hf, Wf, c1x, c1y, TapNone(), bx, by);
-  else bilinear2(bwd, Hf, Wf, c1x, c1y, TapNormFlow{wd1, ht1}, bx, by);     // :279
-  cx = fnx + bx; cy = fny + by;                                             // :280
-  const float cyc = cx * cx + cy * cy;                                      // :294
-  const float eps = alpha1 * ((fnx * fnx + fny * fny) + (bx * bx + by * by)) + a2;   // :295
-  return inside && ((cyc - eps) <= 0.f);                                    // :297
+  if (is_norm) bilinear2(bwd, Hf, Wf, h.c1x, h.c1y, TapNone(), bx, by);
+  else bilinear2(bwd, Hf, Wf, h.c1x, h.c1y, TapNormFlow{(float)(Wf - 1), (float)(Hf - 1)}, bx, by);
+  return fbc_tail(h, bx, by, alpha1, a2, cx, cy);
 }
 
 // alpha_2 / sqrt(h^2+w^2): torch.sqrt of an int64 tensor -> fp32, .item() -> double (util.py:290-292)
@@ -239,32 +270,121 @@ __host__ __device__ inline float fbc_a2(double alpha2, int Hf, int Wf) {
   return (float)(alpha2 / (double)diag);
 }
 
-// Lazy flow mode (nframe = 2, flow_up): add_optical_flow for one point with the composed flow (= upflow8 of the
-// low-res map, contrast/util.py:303-308) and the consistency mask evaluated ON DEMAND from the 1/8-resolution maps -
-// the same arithmetic, hence the same bits, as sampling the dense tensors k_prepare_up8 would have written.
-//   flow  : bilinear sample of up8(lo_own) at the point          (PixPro.py:64)
+// ---- K6: concat_flow for one pixel.  `Source` yields the t-th flow of sample n as a fetch functor. -------------
+struct Up8Source {     // lo [N,F1,2,h,w] (loader layout), up-sampled lazily
+  const float* lo;
+  int F1, h, w;
+  __device__ __forceinline__ FetchUp8 at(int t, int n) const {
+    const float* p = lo + ((size_t)n * F1 + t) * 2 * h * w;
+    return FetchUp8{p, p + (size_t)h * w, h, w, up8_scale(h), up8_scale(w)};
+  }
+};
+
+template <class Source>
+__device__ __forceinline__ void chain_pixel(const Source& src, int F1, int n, int Hf, int Wf, int y, int x,
+                                            int is_norm, float& ox, float& oy) {
+  const float wd1 = (float)(Wf - 1), ht1 = (float)(Hf - 1);
+  if (F1 == 1) {                                   // util.py:303-308: a copy of the only flow
+    src.at(0, n)(y, x, ox, oy);
+    if (is_norm) { ox = 2.f * ox / wd1; oy = 2.f * oy / ht1; }
+    return;
+  }
+  const float x0 = (float)x, y0 = (float)y;
+  const float x0n = 2.f * x0 / wd1 - 1.f, y0n = 2.f * y0 / ht1 - 1.f;   // normalize_coord, util.py:333-339
+  if (is_norm) {                                   // util.py:316-319
+    float cx = x0n, cy = y0n;
+    for (int t = 0; t < F1; ++t) {
+      float fx, fy;
+      bilinear2(src.at(t, n), Hf, Wf, cx, cy, TapNormFlow{wd1, ht1}, fx, fy);
+      cx = cx + fx; cy = cy + fy;
+    }
+    ox = cx - x0n; oy = cy - y0n;
+  } else {                                         // util.py:320-323
+    float cx = x0, cy = y0;
+    for (int t = 0; t < F1; ++t) {
+      float fx, fy;
+      bilinear2(src.at(t, n), Hf, Wf, 2.f * cx / wd1 - 1.f, 2.f * cy / ht1 - 1.f, TapNone(), fx, fy);
+      cx = cx + fx; cy = cy + fy;
+    }
+    ox = cx - x0; oy = cy - y0;
+  }
+}
+
+// ---- Lazy flow mode (flow_up): add_optical_flow for one point with the composed flow (upflow8 + concat_flow of the
+// low-res stack, contrast/util.py:183-194) and the consistency mask (:206-222) evaluated ON DEMAND from the
+// 1/8-resolution maps - the same arithmetic, hence the same bits, as sampling the dense tensors
+// pixpro_flow_prepare would have written.
+//   flow  : bilinear sample of the composed own flow at the point      (PixPro.py:64)  -> 4 pixels of it
 //   valid : mask at the nearest pixel (PixPro.py:68-70) = forward_backward_consistency of that ONE pixel
-__device__ __forceinline__ void displace_point_lazy(const float* __restrict__ lo_own, const float* __restrict__ lo_opp,
-                                                    int h, int w, bool with_mask, float alpha1, double alpha2,
-                                                    const FlowGeom& g, float x, float y, float& ox, float& oy,
-                                                    bool& valid) {
-  const size_t hw = (size_t)h * w;
-  const FetchUp8 own{lo_own, lo_own + hw, h, w, up8_scale(h), up8_scale(w)};
-  const float gx = 2.f * (x / g.wo1) - 1.f;
-  const float gy = 2.f * (y / g.ho1) - 1.f;
-  float fx, fy;
-  bilinear2(own, g.Hf, g.Wf, gx, gy, TapNone(), fx, fy);
+//           -> the own flow there + the opposite flow at the 4 taps of its displaced position
+// Nine composed-flow pixels per point, split in two stages so that a kernel can spread them over lanes:
+//   stage A, s = 0..3: own flow at tap s of the point; s = 4: own flow at the nearest pixel
+//   stage B, s = 0..3: opposite flow (normalised) at tap s of the nearest pixel's displaced position
+struct LazySrc {
+  const float* own;   // this sample's [F1][2][h][w] of this direction
+  const float* opp;   // ... of the opposite direction
+  int F1, h, w;
+  bool with_mask;
+  float alpha1, a2;
+};
+struct LazyPoint {
+  float gx, gy;       // normalised sample position
+  BilinGeom b;        // its bilinear taps in the composed map
+  int xr, yr;         // nearest pixel
+  bool near_in;       // ... lies inside the map
+};
+__device__ __forceinline__ LazyPoint lazy_point(const FlowGeom& g, float x, float y) {
+  LazyPoint p;
+  p.gx = 2.f * (x / g.wo1) - 1.f;
+  p.gy = 2.f * (y / g.ho1) - 1.f;
+  p.b = bilin_geom(g.Hf, g.Wf, p.gx, p.gy);
+  const float ix = (p.gx + 1.f) * ((float)(g.Wf - 1) / 2.f);
+  const float iy = (p.gy + 1.f) * ((float)(g.Hf - 1) / 2.f);
+  const float xr = rintf(ix), yr = rintf(iy);
+  p.near_in = xr >= 0.f && xr < (float)g.Wf && yr >= 0.f && yr < (float)g.Hf;
+  p.xr = p.near_in ? (int)xr : 0;
+  p.yr = p.near_in ? (int)yr : 0;
+  return p;
+}
+__device__ __forceinline__ void lazy_flow_at(const float* lo, const LazySrc& s, const FlowGeom& g, int y, int x,
+                                             float& vx, float& vy) {
+  chain_pixel(Up8Source{lo, s.F1, s.h, s.w}, s.F1, 0, g.Hf, g.Wf, y, x, 0, vx, vy);
+}
+__device__ __forceinline__ void lazy_stage_a(const LazySrc& s, const FlowGeom& g, const LazyPoint& p, int k, float& vx,
+                                             float& vy) {
+  vx = 0.f; vy = 0.f;
+  if (k < 4) {
+    if ((p.b.in >> k) & 1) lazy_flow_at(s.own, s, g, p.b.y0 + (k >> 1), p.b.x0 + (k & 1), vx, vy);
+  } else if (s.with_mask && p.near_in) {
+    lazy_flow_at(s.own, s, g, p.yr, p.xr, vx, vy);
+  }
+}
+__device__ __forceinline__ void lazy_stage_b(const LazySrc& s, const FlowGeom& g, const LazyPoint& p, float px, float py,
+                                             int k, float& vx, float& vy) {
+  vx = 0.f; vy = 0.f;
+  if (!(s.with_mask && p.near_in)) return;
+  const FbcHead h = fbc_head(px, py, g.Hf, g.Wf, p.yr, p.xr, 0);
+  const BilinGeom b = bilin_geom(g.Hf, g.Wf, h.c1x, h.c1y);
+  if ((b.in >> k) & 1) {
+    lazy_flow_at(s.opp, s, g, b.y0 + (k >> 1), b.x0 + (k & 1), vx, vy);
+    const TapNormFlow tap{(float)(g.Wf - 1), (float)(g.Hf - 1)};
+    vx = tap.x(vx); vy = tap.y(vy);
+  }
+}
+// A: stage-A results {x,y} x 5, B: stage-B results {x,y} x 4 (registers or LDS)
+__device__ __forceinline__ void lazy_finish(const LazySrc& s, const FlowGeom& g, const LazyPoint& p, float x, float y,
+                                            const float* A, const float* B, float& ox, float& oy, bool& valid) {
+  const float fx = bilin_combine(p.b, A[0], A[2], A[4], A[6]);
+  const float fy = bilin_combine(p.b, A[1], A[3], A[5], A[7]);
   valid = true;
-  if (with_mask) {
-    const float ix = (gx + 1.f) * ((float)(g.Wf - 1) / 2.f);
-    const float iy = (gy + 1.f) * ((float)(g.Hf - 1) / 2.f);
-    const float xr = rintf(ix), yr = rintf(iy);
+  if (s.with_mask) {
     valid = false;
-    if (xr >= 0.f && xr < (float)g.Wf && yr >= 0.f && yr < (float)g.Hf) {
-      const FetchUp8 opp{lo_opp, lo_opp + hw, h, w, up8_scale(h), up8_scale(w)};
-      float px, py, cx, cy;
-      own((int)yr, (int)xr, px, py);
-      valid = fbc_pixel(px, py, opp, g.Hf, g.Wf, (int)yr, (int)xr, alpha1, fbc_a2(alpha2, g.Hf, g.Wf), 0, cx, cy);
+    if (p.near_in) {
+      const FbcHead h = fbc_head(A[8], A[9], g.Hf, g.Wf, p.yr, p.xr, 0);
+      const BilinGeom b = bilin_geom(g.Hf, g.Wf, h.c1x, h.c1y);
+      float cx, cy;
+      valid = fbc_tail(h, bilin_combine(b, B[0], B[2], B[4], B[6]), bilin_combine(b, B[1], B[3], B[5], B[7]), s.alpha1,
+                       s.a2, cx, cy);
     }
   }
   if (g.diff) {
@@ -274,6 +394,23 @@ __device__ __forceinline__ void displace_point_lazy(const float* __restrict__ lo
     ox = x + fx;
     oy = y + fy;
   }
+}
+// all nine pixels on one lane (staged path, and the single-frame case of the fused kernel)
+__device__ __forceinline__ void displace_point_lazy(const LazySrc& s, const FlowGeom& g, float x, float y, float& ox,
+                                                    float& oy, bool& valid) {
+  const LazyPoint p = lazy_point(g, x, y);
+  float A[10], B[8];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) lazy_stage_a(s, g, p, k, A[2 * k], A[2 * k + 1]);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) lazy_stage_b(s, g, p, A[8], A[9], k, B[2 * k], B[2 * k + 1]);
+  lazy_finish(s, g, p, x, y, A, B, ox, oy, valid);
+}
+__device__ __forceinline__ LazySrc lazy_src(const pixpro_problem& pb, const pixpro_dir& d, int n) {
+  const int F1 = pb.lo_frames > 1 ? pb.lo_frames : 1;
+  const size_t off = (size_t)n * F1 * 2 * pb.lo_h * pb.lo_w;
+  return LazySrc{d.lo_own + off, d.lo_opp + off, F1, pb.lo_h, pb.lo_w, pb.lazy_mask != 0, pb.alpha1,
+                 fbc_a2(pb.alpha2, 8 * pb.lo_h, 8 * pb.lo_w)};
 }
 
 // Frame size for one problem: explicit device tensor, explicit ints, or coord_q[0][9], [0][8].

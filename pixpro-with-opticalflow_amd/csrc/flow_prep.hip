@@ -35,14 +35,6 @@ struct DenseSource {   // flows [F1,N,2,Hf,Wf]
     return FetchDense{p, p + (size_t)Hf * Wf, Wf};
   }
 };
-struct Up8Source {     // lo [N,F1,2,h,w] (loader layout), up-sampled lazily
-  const float* lo;
-  int F1, h, w;
-  __device__ __forceinline__ FetchUp8 at(int t, int n) const {
-    const float* p = lo + ((size_t)n * F1 + t) * 2 * h * w;
-    return FetchUp8{p, p + (size_t)h * w, h, w, up8_scale(h), up8_scale(w)};
-  }
-};
 struct LoSource {      // lo [N,F1,2,h,w] used at its own resolution (flow_up == False)
   const float* lo;
   int F1, h, w;
@@ -51,36 +43,6 @@ struct LoSource {      // lo [N,F1,2,h,w] used at its own resolution (flow_up ==
     return FetchDense{p, p + (size_t)h * w, w};
   }
 };
-
-template <class Source>
-__device__ __forceinline__ void chain_pixel(const Source& src, int F1, int n, int Hf, int Wf, int y, int x,
-                                            int is_norm, float& ox, float& oy) {
-  const float wd1 = (float)(Wf - 1), ht1 = (float)(Hf - 1);
-  if (F1 == 1) {                                   // util.py:303-308: a copy of the only flow
-    src.at(0, n)(y, x, ox, oy);
-    if (is_norm) { ox = 2.f * ox / wd1; oy = 2.f * oy / ht1; }
-    return;
-  }
-  const float x0 = (float)x, y0 = (float)y;
-  const float x0n = 2.f * x0 / wd1 - 1.f, y0n = 2.f * y0 / ht1 - 1.f;   // normalize_coord, util.py:333-339
-  if (is_norm) {                                   // util.py:316-319
-    float cx = x0n, cy = y0n;
-    for (int t = 0; t < F1; ++t) {
-      float fx, fy;
-      bilinear2(src.at(t, n), Hf, Wf, cx, cy, TapNormFlow{wd1, ht1}, fx, fy);
-      cx = cx + fx; cy = cy + fy;
-    }
-    ox = cx - x0n; oy = cy - y0n;
-  } else {                                         // util.py:320-323
-    float cx = x0, cy = y0;
-    for (int t = 0; t < F1; ++t) {
-      float fx, fy;
-      bilinear2(src.at(t, n), Hf, Wf, 2.f * cx / wd1 - 1.f, 2.f * cy / ht1 - 1.f, TapNone(), fx, fy);
-      cx = cx + fx; cy = cy + fy;
-    }
-    ox = cx - x0; oy = cy - y0;
-  }
-}
 
 template <class Source>
 __global__ void k_chain(Source s0, Source s1, float* __restrict__ out0, float* __restrict__ out1, int F1, int N,

@@ -368,6 +368,36 @@ ppm_fused_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* _
   LOAD_TILE(pfa, gx);
   LOAD_TILE(pfb, gv);
   if (tid < 4) { sm.B0[tile + tid] = 0.f; sm.B1[tile + tid] = 0.f; }
+  // lazy flow mode with a chain (nframe > 2): the nine composed-flow pixels each point needs (common.h) are spread over
+  // the work-group, two dependent stages through LDS (the AA matrix is not live yet), so that a point costs two chain
+  // latencies instead of nine
+  const bool lazy_spread = dd.lo_own != nullptr && pb.lo_frames > 1;
+  if (lazy_spread) {
+    int Ho, Wo;
+    frame_size(pb, dd, Ho, Wo);
+    const float wo1 = (float)(Wo - 1), ho1 = (float)(Ho - 1);
+    const Crop cq = crop_of(dd.coord_q + (size_t)n * 10, pb.H, pb.W);
+    const FlowGeom fg = flow_geom(8 * pb.lo_h, 8 * pb.lo_w, Ho, Wo);
+    const LazySrc ls = lazy_src(pb, dd, n);
+    float* LA = sm.AA;
+    float* LB = sm.AA + 10 * P;
+    for (int e = tid; e < 5 * P; e += NTHREADS) {
+      const int pt = e / 5, k = e % 5;
+      const LazyPoint lp = lazy_point(fg, centre_x(cq, pt % pb.W, wo1), centre_y(cq, pt / pb.W, ho1));
+      float vx, vy;
+      lazy_stage_a(ls, fg, lp, k, vx, vy);
+      LA[2 * e] = vx; LA[2 * e + 1] = vy;
+    }
+    __syncthreads();
+    for (int e = tid; e < 4 * P; e += NTHREADS) {
+      const int pt = e / 4, k = e % 4;
+      const LazyPoint lp = lazy_point(fg, centre_x(cq, pt % pb.W, wo1), centre_y(cq, pt / pb.W, ho1));
+      float vx, vy;
+      lazy_stage_b(ls, fg, lp, LA[10 * pt + 8], LA[10 * pt + 9], k, vx, vy);
+      LB[2 * e] = vx; LB[2 * e + 1] = vy;
+    }
+    __syncthreads();
+  }
   if (tid < 64) {
     float qx = 0.f, qy = 0.f, kx = 0.f, ky = 0.f;
     int valid = 0;
@@ -383,10 +413,10 @@ ppm_fused_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* _
       bool v = true;
       if (dd.lo_own) {          // lazy flow mode: evaluate flow + validity at this point from the low-res maps
         const FlowGeom fg = flow_geom(8 * pb.lo_h, 8 * pb.lo_w, Ho, Wo);
-        const size_t lo = (size_t)n * 2 * pb.lo_h * pb.lo_w;
+        const LazySrc ls = lazy_src(pb, dd, n);
         float ox, oy;
-        displace_point_lazy(dd.lo_own + lo, dd.lo_opp + lo, pb.lo_h, pb.lo_w, pb.lazy_mask != 0, pb.alpha1, pb.alpha2,
-                            fg, qx, qy, ox, oy, v);
+        if (lazy_spread) lazy_finish(ls, fg, lazy_point(fg, qx, qy), qx, qy, sm.AA + 10 * tid, sm.AA + 10 * P + 8 * tid, ox, oy, v);
+        else displace_point_lazy(ls, fg, qx, qy, ox, oy, v);
         qx = ox; qy = oy;
       } else if (dd.flow) {
         const FlowGeom fg = flow_geom(pb.Hf, pb.Wf, Ho, Wo);

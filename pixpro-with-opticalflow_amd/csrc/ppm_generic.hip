@@ -143,10 +143,8 @@ __global__ void k_points(pixpro_problem pb, Dirs D, float* __restrict__ pts, flo
   bool valid = true;
   if (dd.lo_own) {            // lazy flow mode (see common.h)
     const FlowGeom fg = flow_geom(8 * pb.lo_h, 8 * pb.lo_w, Ho, Wo);
-    const size_t lo = (size_t)n * 2 * pb.lo_h * pb.lo_w;
     float ox, oy;
-    displace_point_lazy(dd.lo_own + lo, dd.lo_opp + lo, pb.lo_h, pb.lo_w, pb.lazy_mask != 0, pb.alpha1, pb.alpha2, fg,
-                        qx, qy, ox, oy, valid);
+    displace_point_lazy(lazy_src(pb, dd, n), fg, qx, qy, ox, oy, valid);
     qx = ox; qy = oy;
   } else if (dd.flow) {
     const FlowGeom fg = flow_geom(pb.Hf, pb.Wf, Ho, Wo);

@@ -25,7 +25,7 @@ def test_header_symbols_exported_and_bound():
 
 def test_struct_layout_matches_header():
     from contrast import _native
-    assert ctypes.sizeof(_native.Problem) == 88          # 19 x 4 B, padding, one double
+    assert ctypes.sizeof(_native.Problem) == 88          # 20 x 4 B, one double
     assert ctypes.sizeof(_native.Dir) == 13 * ctypes.sizeof(ctypes.c_void_p)
 
 

@@ -261,13 +261,19 @@ def test_channels_last_tiles_consumed_in_place(dev, shape):
         assert nv.is_nhwc(v) and torch.equal(u, v)
 
 
-@pytest.mark.parametrize("shape,frame,lo,sigma,masked", [
-    ((6, 256, 7, 7), (96, 128), (12, 16), 0.5, True), ((4, 256, 7, 7), (720, 1280), (90, 160), 0.5, True),
-    ((4, 256, 7, 7), (96, 128), (12, 16), 6.0, True), ((3, 128, 7, 7), (96, 128), (12, 16), 0.5, False),
-    ((2, 64, 14, 14), (96, 128), (12, 16), 1.0, True),            # staged path
-    ((4, 256, 7, 7), (192, 256), (12, 16), 0.5, True),            # flow map at half the frame size (ratio branch)
+@pytest.mark.parametrize("shape,frame,lo,sigma,masked,F1", [
+    ((6, 256, 7, 7), (96, 128), (12, 16), 0.5, True, 1), ((4, 256, 7, 7), (720, 1280), (90, 160), 0.5, True, 1),
+    ((4, 256, 7, 7), (96, 128), (12, 16), 6.0, True, 1), ((3, 128, 7, 7), (96, 128), (12, 16), 0.5, False, 1),
+    ((2, 64, 14, 14), (96, 128), (12, 16), 1.0, True, 1),            # staged path
+    ((4, 256, 7, 7), (192, 256), (12, 16), 0.5, True, 1),            # flow map at half the frame size (ratio branch)
+    # chains (nframe = 3, 6): the nine composed-flow pixels per point are spread over the work-group
+    ((5, 256, 7, 7), (96, 128), (12, 16), 0.5, True, 2), ((4, 256, 7, 7), (720, 1280), (90, 160), 0.5, True, 5),
+    ((4, 256, 7, 7), (96, 128), (12, 16), 4.0, True, 5), ((3, 128, 7, 7), (96, 128), (12, 16), 0.5, False, 3),
+    ((2, 64, 14, 14), (96, 128), (12, 16), 1.0, True, 3),            # staged path, one lane per point
+    ((3, 256, 8, 8), (96, 128), (12, 16), 1.0, True, 2),             # P = 64 on the staged path (LDS)
+    ((3, 128, 8, 8), (96, 128), (12, 16), 1.0, True, 2),             # P = 64, fused: 320 stage-A items
 ])
-def test_lazy_flow_equals_dense(dev, shape, frame, lo, sigma, masked):
+def test_lazy_flow_equals_dense(dev, shape, frame, lo, sigma, masked, F1):
     """--lazy-flow: flow + consistency mask evaluated inside the loss kernel at its P sample points from the 1/8-res
     maps must reproduce the dense pipeline (apply_optical_flow -> dense tensors -> loss) bit for bit."""
     import types
@@ -281,10 +287,10 @@ def test_lazy_flow_equals_dense(dev, shape, frame, lo, sigma, masked):
     c1 = crop_coords(N, frame[1], frame[0], rng).to(dev)
     c2 = (c1 + 0.0).clone()
     c2[:, :4] = (c1[:, :4] + 0.02 * torch.randn(N, 4, generator=gen).to(dev))
-    lo_f = smooth_flow((N, 1, 2, *lo), sigma, gen).to(dev)
-    lo_b = (-lo_f + smooth_flow((N, 1, 2, *lo), 0.1 * sigma, gen).to(dev)).contiguous()
+    lo_f = smooth_flow((N, F1, 2, *lo), sigma, gen).to(dev)
+    lo_b = (-lo_f.flip(1) + smooth_flow((N, F1, 2, *lo), 0.1 * sigma, gen).to(dev)).contiguous()
     size = torch.tensor(list(frame), device=dev)
-    data = [None] * 5 + [[None, lo_f, lo_b], [size.repeat(N, 1), torch.full((N, 1), 2, device=dev)]]
+    data = [None] * 5 + [[None, lo_f, lo_b], [size.repeat(N, 1), torch.full((N, 1), F1 + 1, device=dev)]]
     a1, a2 = (0.01, 0.5) if masked else (None, None)
     base = dict(use_flow_file=True, use_flow_frames=False, flow_cat_norm=False, flow_up=True, alpha1=a1, alpha2=a2, debug=False)
     dense_f, dense_b = util.apply_optical_flow(data, None, types.SimpleNamespace(lazy_flow=False, **base))
