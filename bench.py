@@ -220,6 +220,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # PIXPRO_REHEARSAL=1: all ranks share the visible GPU(s) and talk over gloo.  Only for rehearsing the N>1 control
+    # flow (DDP buckets, SyncBN exchanges, shard seeds, max-over-ranks timing) on a one-GPU box; never a measurement.
+    rehearsal = os.environ.get("PIXPRO_REHEARSAL") == "1"
+    if rehearsal:
+        local %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1 or os.environ.get("PIXPRO_FORCE_DDP") == "1":
@@ -228,7 +233,7 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group(backend="nccl", init_method="env://")
+        dist.init_process_group(backend="gloo" if rehearsal else "nccl", init_method="env://")
     import main_pretrain
     from contrast import ops, util
     from contrast.lr_scheduler import get_scheduler
@@ -326,7 +331,8 @@ def main():
                                    f"p=2, transform_layer=1, LARS, fp32",
                        "flow_mode": "lazy (flow + mask evaluated at the loss sample points)" if a.lazy_flow else "dense",
                        "per_gpu_batch": a.batch, "global_batch": a.batch * world,
-                       "parallelism": f"dp{world}" if world > 1 else "single", "final_loss": round(final_loss, 5)},
+                       "parallelism": f"dp{world}" if world > 1 else "single", "final_loss": round(final_loss, 5),
+                       **({"rehearsal": "gloo, ranks share one GPU: not a measurement"} if rehearsal else {})},
             "roofline": dict(kernel=dominant, **kernels[dominant]) if dominant else None,
             "hot_kernels": kernels,
         }
