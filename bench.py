@@ -57,6 +57,8 @@ def parse():
     ap.add_argument("--lazy-flow", action="store_true",
                     help="skip the dense flow preparation, evaluate flow chain + mask inside the loss kernel "
                          "(same results; the default keeps the reference's dense pipeline, which BASELINE's metric names)")
+    ap.add_argument("--fused-bn", action="store_true",
+                    help="HIP (Sync)BatchNorm with ReLU / residual add folded in instead of torch's (Sync)BatchNorm + ReLU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-flow-images", type=int, default=8)
     ap.add_argument("--no-channels-last", dest="channels_last", action="store_false",
@@ -81,6 +83,8 @@ def model_args(a, world):
         argv.append("--channels-last")
     if a.lazy_flow:
         argv.append("--lazy-flow")
+    if a.fused_bn:
+        argv.append("--fused-bn")
     args = option.parse_option(argv=argv)
     args.num_instances = 70000
     return args
@@ -329,6 +333,7 @@ def main():
             "config": {"workload": f"{a.arch} PixPro+optical-flow pre-train step, {a.image_size}x{a.image_size} crops, "
                                    f"nframe={a.n_frames}, 720x1280 frames, file-mode flow (flow_up, alpha1=0.01, alpha2=0.5), "
                                    f"p=2, transform_layer=1, LARS, fp32",
+                       "batch_norm": "fused HIP SyncBN+ReLU" if a.fused_bn else "torch (Sync)BatchNorm",
                        "flow_mode": "lazy (flow + mask evaluated at the loss sample points)" if a.lazy_flow else "dense",
                        "per_gpu_batch": a.batch, "global_batch": a.batch * world,
                        "parallelism": f"dp{world}" if world > 1 else "single", "final_loss": round(final_loss, 5),

@@ -177,6 +177,39 @@ int pixpro_lars_sgd_step(float* const* p_ptrs, const float* const* g_ptrs,
                          float trust_coef, float eps, int32_t first_step, float* norms2,
                          void* stream);
 
+/* ---- (Sync)BatchNorm with ReLU / residual add folded in ----------
+ * Replaces what torch.nn.SyncBatchNorm (installed by contrast/models/PixPro.py:289-292) runs per layer in training mode
+ * (torch/nn/modules/_functions.py: batch_norm_stats, batch_norm_gather_stats_with_counts, batch_norm_elemt,
+ * batch_norm_backward_reduce, batch_norm_backward_elemt) plus the F.relu / `out += identity` that follow it in the
+ * ResNet blocks (contrast/resnet.py).  Activations are NHWC fp32 seen as [rows = N*H*W][C], C % 4 == 0; the collectives
+ * between the calls stay with the caller (torch.distributed over RCCL):
+ *   forward : pixpro_bn_stats -> all_gather(packed [2C+1]) -> pixpro_bn_apply
+ *   backward: pixpro_bn_backward_reduce -> all_reduce(sums [2C]) -> pixpro_bn_backward_apply                         */
+size_t pixpro_bn_workspace_bytes(int64_t rows, int32_t C);
+/* packed[0..C) = mean, packed[C..2C) = biased variance, packed[2C] = rows: this rank's statistics. */
+int pixpro_bn_stats(const float* x, int64_t rows, int32_t C, void* workspace, size_t workspace_bytes,
+                    float* packed, void* stream);
+/* gathered [world][2C+1]: the packed statistics of all ranks.  Writes mean, invstd [C] (saved for backward), updates
+ * running_mean / running_var (nullable) with `momentum` (unbiased variance), and
+ * y = relu?( (x - mean) * invstd * weight + bias (+ residual) ).  weight/bias/residual nullable.
+ * scale_shift: scratch float[2C]. */
+int pixpro_bn_apply(const float* gathered, int32_t world, const float* x, const float* residual,
+                    const float* weight, const float* bias, float* running_mean, float* running_var,
+                    float momentum, float eps, int32_t relu, int64_t rows, int32_t C, float* y,
+                    float* mean, float* invstd, float* scale_shift, void* stream);
+/* dz = dy * (y > 0) if relu else dy.  sums[0..C) = sum dz, sums[C..2C) = sum dz*(x-mean) of this rank;
+ * grad_weight = sums[C..2C) * invstd, grad_bias = sums[0..C) (nullable). */
+int pixpro_bn_backward_reduce(const float* dy, const float* x, const float* y, const float* mean,
+                              const float* invstd, int32_t relu, int64_t rows, int32_t C,
+                              void* workspace, size_t workspace_bytes, float* sums,
+                              float* grad_weight, float* grad_bias, void* stream);
+/* sums: totals over all ranks, count: total rows over all ranks.
+ * dx = (dz - sum_dz/count - (x-mean)*invstd^2*sum_dz_xmu/count) * invstd * weight;  dresidual = dz (nullable). */
+int pixpro_bn_backward_apply(const float* dy, const float* x, const float* y, const float* mean,
+                             const float* invstd, const float* weight, const float* sums, double count,
+                             int32_t relu, int64_t rows, int32_t C, float* dx, float* dresidual,
+                             void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -25,6 +25,7 @@ from torch.distributed import get_world_size, is_initialized
 
 from .. import ops
 from ..multi_tensor import ema_update
+from ..sync_bn import FusedSyncBatchNorm, bn_act
 from .base import BaseModel
 
 
@@ -48,7 +49,7 @@ class MLP2d(nn.Module):
         self.linear2 = conv1x1(inner_dim, out_dim)
 
     def forward(self, x):
-        return self.linear2(self.relu1(self.bn1(self.linear1(x))))
+        return self.linear2(bn_act(self.bn1, self.linear1(x), relu=True))
 
 
 def Proj_Head(in_dim=2048, inner_dim=4096, out_dim=256):
@@ -113,9 +114,12 @@ class PixPro(BaseModel):
         self._tie(self.projector, self.projector_k)
 
         sync_bn = getattr(args, "sync_bn", True)
-        if sync_bn:  # PixPro.py:289-292 (in-place on the children)
+        # PixPro.py:289-292 (in-place on the children).  --fused-bn: the HIP SyncBN with ReLU / residual add folded in
+        self._convert_bn = (FusedSyncBatchNorm.convert if getattr(args, "fused_bn", False)
+                            else nn.SyncBatchNorm.convert_sync_batchnorm)
+        if sync_bn:
             for m in (self.encoder, self.encoder_k, self.projector, self.projector_k):
-                nn.SyncBatchNorm.convert_sync_batchnorm(m)
+                self._convert_bn(m)
 
         world = get_world_size() if is_initialized() else 1
         per_epoch = args.num_instances * 1. / world / args.batch_size
@@ -138,7 +142,7 @@ class PixPro(BaseModel):
             self._tie(self.projector_instance, self.projector_instance_k)
             if sync_bn:
                 for m in (self.projector_instance, self.projector_instance_k, self.predictor):
-                    nn.SyncBatchNorm.convert_sync_batchnorm(m)
+                    self._convert_bn(m)
             self.avgpool = nn.AdaptiveAvgPool2d(1)   # reference hard-codes AvgPool2d(7) (defect D4)
 
     @staticmethod

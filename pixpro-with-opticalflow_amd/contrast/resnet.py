@@ -10,6 +10,8 @@ import math
 
 import torch.nn as nn
 
+from .sync_bn import bn_act
+
 ARCHS = {
     # name: (block, depths, extra kwargs)
     "resnet18": ("basic", (2, 2, 2, 2), {}),
@@ -56,12 +58,13 @@ class _Residual(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        out = self.relu(self.bn1(self.conv1(x)))
-        out = self.bn2(self.conv2(out))
-        if self.kind != "basic":
-            out = self.bn3(self.conv3(self.relu(out)))
-        out = out + (x if self.downsample is None else self.downsample(x))
-        return self.relu(out)
+        # bn_act(bn, t, relu, residual) = relu?(bn(t) (+ residual)): one fused launch pair with FusedSyncBatchNorm
+        identity = x if self.downsample is None else self.downsample(x)
+        out = bn_act(self.bn1, self.conv1(x), relu=True)
+        if self.kind == "basic":
+            return bn_act(self.bn2, self.conv2(out), relu=True, residual=identity)
+        out = bn_act(self.bn2, self.conv2(out), relu=True)
+        return bn_act(self.bn3, self.conv3(out), relu=True, residual=identity)
 
 
 class ResNet(nn.Module):
@@ -129,7 +132,7 @@ class ResNet(nn.Module):
                 nn.init.zeros_((m.bn2 if m.kind == "basic" else m.bn3).weight)
 
     def forward(self, x):
-        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = self.maxpool(bn_act(self.bn1, self.conv1(x), relu=True))
         c2 = self.layer1(x)
         c3 = self.layer2(c2)
         c4 = self.layer3(c3)

@@ -1,0 +1,169 @@
+"""(Sync)BatchNorm on the HIP library with the ReLU / residual add of the ResNet blocks folded in.
+
+The reference turns every BatchNorm of the encoders and projectors into `torch.nn.SyncBatchNorm`
+(contrast/models/PixPro.py:289-292).  With more than one rank that module runs ATen's native kernels instead of MIOpen
+(torch/nn/modules/_functions.py:SyncBatchNorm), which is ~3x slower on MI355X (profiles/r01_syncbn_microbench.txt), and
+every BN is followed by a separate ReLU (and, at the end of a residual unit, a separate add).  `FusedSyncBatchNorm`
+keeps torch's split - local statistics | all_gather | normalise ; local sums | all_reduce | input gradient - so the
+collectives and their payloads ([2C+1] and [2C] floats per layer) are exactly torch's, but the element-wise passes are
+the streaming kernels of csrc/sync_bn.hip:
+
+    y = relu?( batch_norm(x) (+ residual) )                    3 (4) tensor passes instead of 5 (8)
+    backward: dz = dy * (y > 0)?; dx, dweight, dbias, dresidual = dz
+
+Parameter / buffer names are those of `nn.BatchNorm2d` (`weight, bias, running_mean, running_var, num_batches_tracked`),
+so checkpoints load either way.  Activations must be channels_last (the layout the encoders run in); CPU tensors raise.
+"""
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _native as nv
+
+
+def _rows_view(t, name):
+    """[N,C,H,W] channels_last-dense (or any layout when H = W = 1) -> (tensor, rows, C)."""
+    if t.dim() == 2:
+        t = t if t.is_contiguous() else t.contiguous()
+        return t, t.shape[0], t.shape[1]
+    if t.dim() != 4:
+        raise RuntimeError(f"{name}: expected [N,C,H,W] or [N,C], got {tuple(t.shape)}")
+    if not t.is_cuda or t.dtype != torch.float32:
+        raise RuntimeError(f"{name}: FusedSyncBatchNorm runs on fp32 GPU tensors only (got {t.dtype} on {t.device}); "
+                           "there is no CPU fallback")
+    if not t.is_contiguous(memory_format=torch.channels_last):
+        t = t.contiguous(memory_format=torch.channels_last)
+    return t, t.shape[0] * t.shape[2] * t.shape[3], t.shape[1]
+
+
+def _world(group):
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1
+    return dist.get_world_size(group)
+
+
+class _FusedBN(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, running_mean, running_var, momentum, eps, relu, group):
+        x, rows, C = _rows_view(x, "input")
+        if not x.is_cuda or x.dtype != torch.float32:
+            raise RuntimeError("FusedSyncBatchNorm runs on fp32 GPU tensors only; there is no CPU fallback")
+        if residual is not None:
+            residual, r_rows, r_C = _rows_view(residual, "residual")
+            if (r_rows, r_C) != (rows, C):
+                raise RuntimeError(f"residual shape {tuple(residual.shape)} does not match input {tuple(x.shape)}")
+        dev = x.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        wsb = nv.load().pixpro_bn_workspace_bytes(rows, C)
+        if wsb == 0:
+            raise RuntimeError(f"FusedSyncBatchNorm: unsupported shape rows={rows}, C={C} (C must be a multiple of 4)")
+        ws = nv.workspace(wsb, dev)
+        packed = torch.empty(2 * C + 1, **f32)
+        nv.call("pixpro_bn_stats", nv.ptr(x), rows, C, nv.ptr(ws), wsb, nv.ptr(packed), nv.stream())
+        world = _world(group)
+        if world > 1:
+            gathered = torch.empty(world, 2 * C + 1, **f32)
+            if dist.get_backend(group) == "gloo":      # rehearsal / tests: no all_gather_into_tensor on gloo
+                parts = list(gathered.unbind(0))
+                dist.all_gather(parts, packed, group=group)
+                gathered = torch.stack(parts)
+            else:
+                dist.all_gather_into_tensor(gathered, packed, group=group)
+        else:
+            gathered = packed
+        y = torch.empty_like(x)
+        mean, invstd, scale_shift = torch.empty(C, **f32), torch.empty(C, **f32), torch.empty(2 * C, **f32)
+        nv.call("pixpro_bn_apply", nv.ptr(gathered), world, nv.ptr(x), nv.ptr(residual), nv.ptr(weight), nv.ptr(bias),
+                nv.ptr(running_mean), nv.ptr(running_var), float(momentum), float(eps), int(relu), rows, C, nv.ptr(y),
+                nv.ptr(mean), nv.ptr(invstd), nv.ptr(scale_shift), nv.stream())
+        ctx.save_for_backward(x, y if relu else None, weight, mean, invstd)
+        ctx.meta = (rows, C, bool(relu), residual is not None, group, world)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, weight, mean, invstd = ctx.saved_tensors
+        rows, C, relu, has_res, group, world = ctx.meta
+        if dy.dim() == 4 and not dy.is_contiguous(memory_format=torch.channels_last) or dy.dim() == 2 and not dy.is_contiguous():
+            dy = dy.contiguous(memory_format=torch.channels_last) if dy.dim() == 4 else dy.contiguous()
+        dev = x.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        wsb = nv.load().pixpro_bn_workspace_bytes(rows, C)
+        ws = nv.workspace(wsb, dev)
+        sums = torch.empty(2 * C, **f32)
+        need_w = weight is not None and ctx.needs_input_grad[1]
+        need_b = ctx.needs_input_grad[2]
+        gw = torch.empty(C, **f32) if need_w else None
+        gb = torch.empty(C, **f32) if need_b else None
+        nv.call("pixpro_bn_backward_reduce", nv.ptr(dy), nv.ptr(x), nv.ptr(y), nv.ptr(mean), nv.ptr(invstd), int(relu),
+                rows, C, nv.ptr(ws), wsb, nv.ptr(sums), nv.ptr(gw), nv.ptr(gb), nv.stream())
+        if world > 1:
+            dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dres = torch.empty_like(x) if (has_res and ctx.needs_input_grad[3]) else None
+        if dx is None and dres is not None:
+            dx = torch.empty_like(x)
+        if dx is not None:
+            # per-rank batches are equal (the reference's loader drops the last partial batch), so count = world * rows
+            nv.call("pixpro_bn_backward_apply", nv.ptr(dy), nv.ptr(x), nv.ptr(y), nv.ptr(mean), nv.ptr(invstd),
+                    nv.ptr(weight), nv.ptr(sums), float(rows) * world, int(relu), rows, C, nv.ptr(dx), nv.ptr(dres),
+                    nv.stream())
+        return dx, gw, gb, dres, None, None, None, None, None, None
+
+
+class FusedSyncBatchNorm(nn.modules.batchnorm._BatchNorm):
+    """Drop-in for nn.BatchNorm2d / nn.SyncBatchNorm with optional fused tail: `bn(x, residual=None, relu=False)`."""
+
+    fused = True
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, track_running_stats=True, process_group=None):
+        super().__init__(num_features, eps, momentum, affine, track_running_stats)
+        self.process_group = process_group
+        if momentum is None:
+            raise NotImplementedError("cumulative moving average (momentum=None) is not provided")
+
+    def _check_input_dim(self, input):
+        if input.dim() not in (2, 4):
+            raise ValueError(f"expected 2D or 4D input (got {input.dim()}D input)")
+
+    def forward(self, input, residual=None, relu=False):
+        self._check_input_dim(input)
+        if self.training or not self.track_running_stats:
+            if self.training and self.track_running_stats and self.num_batches_tracked is not None:
+                self.num_batches_tracked.add_(1)
+            rm = self.running_mean if (self.training and self.track_running_stats) else None
+            rv = self.running_var if (self.training and self.track_running_stats) else None
+            return _FusedBN.apply(input, self.weight, self.bias, residual, rm, rv, self.momentum, self.eps, relu,
+                                  self.process_group)
+        out = F.batch_norm(input, self.running_mean, self.running_var, self.weight, self.bias, False, 0.0, self.eps)
+        if residual is not None:
+            out = out + residual
+        return F.relu(out) if relu else out
+
+    @classmethod
+    def convert(cls, module, process_group=None):
+        """Replace every BatchNorm / SyncBatchNorm below `module` (in place on the children, like
+        nn.SyncBatchNorm.convert_sync_batchnorm); parameters and buffers are shared, not copied."""
+        out = module
+        if isinstance(module, nn.modules.batchnorm._BatchNorm) and not isinstance(module, cls):
+            out = cls(module.num_features, module.eps, module.momentum, module.affine, module.track_running_stats,
+                      process_group)
+            if module.affine:
+                out.weight, out.bias = module.weight, module.bias
+            out.running_mean, out.running_var = module.running_mean, module.running_var
+            out.num_batches_tracked = module.num_batches_tracked
+            out.training = module.training
+        for name, child in module.named_children():
+            out.add_module(name, cls.convert(child, process_group))
+        return out
+
+
+def bn_act(bn, x, relu=False, residual=None):
+    """`relu?(bn(x) (+ residual))` through the fused module when `bn` is one, through the stock ops otherwise."""
+    if getattr(bn, "fused", False):
+        return bn(x, residual, relu)
+    out = bn(x)
+    if residual is not None:
+        out = out + residual
+    return F.relu(out, inplace=True) if relu else out

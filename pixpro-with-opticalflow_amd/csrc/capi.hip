@@ -67,6 +67,16 @@ int run_lars(float* const* pp, const float* const* gp, float* const* bp, const i
              const int32_t* adapt, int count, float lr, float momentum, float trust, float eps, int first_step,
              float* norms2, hipStream_t st);
 int run_scale(float* buf, size_t n, const float* scale, hipStream_t st);
+size_t bn_workspace_floats(int64_t M, int C);
+int run_bn_stats(const float* x, int64_t M, int C, float* ws, float* packed, hipStream_t st);
+int run_bn_apply(const float* gathered, int W, const float* x, const float* res, const float* weight, const float* bias,
+                 float* running_mean, float* running_var, float momentum, float eps, int relu, int64_t M, int C,
+                 float* y, float* mean, float* invstd, float* scale_shift, hipStream_t st);
+int run_bn_bwd_reduce(const float* dy, const float* x, const float* y, const float* mean, const float* invstd, int relu,
+                      int64_t M, int C, float* ws, float* sums, float* grad_weight, float* grad_bias, hipStream_t st);
+int run_bn_bwd_apply(const float* dy, const float* x, const float* y, const float* mean, const float* invstd,
+                     const float* weight, const float* sums, double count, int relu, int64_t M, int C, float* dx,
+                     float* dres, hipStream_t st);
 
 namespace {
 
@@ -246,6 +256,63 @@ int pixpro_lars_sgd_step(float* const* p_ptrs, const float* const* g_ptrs, float
   if (count < 1 || count > 65535) return bad("count out of range");
   return run_lars(p_ptrs, g_ptrs, buf_ptrs, sizes, wd, adapt, count, lr, momentum, trust_coef, eps, first_step,
                   norms2, (hipStream_t)stream);
+}
+
+static int bn_shape_ok(int64_t rows, int32_t C) {
+  if (rows < 1 || C < 4 || (C & 3)) return bad("batch norm: rows >= 1 and C a positive multiple of 4 required");
+  if (rows * (int64_t)C / 4 > 0x7fffffffffLL) return bad("batch norm: tensor too large");
+  return PIXPRO_OK;
+}
+
+size_t pixpro_bn_workspace_bytes(int64_t rows, int32_t C) {
+  if (rows < 1 || C < 4 || (C & 3)) return 0;
+  return bn_workspace_floats(rows, C) * sizeof(float);
+}
+
+int pixpro_bn_stats(const float* x, int64_t rows, int32_t C, void* workspace, size_t workspace_bytes, float* packed,
+                    void* stream) {
+  if (!x || !workspace || !packed) return bad("null pointer");
+  if (int e = bn_shape_ok(rows, C)) return e;
+  if (workspace_bytes < pixpro_bn_workspace_bytes(rows, C)) return bad("workspace too small");
+  if ((uintptr_t)x & 15) return bad("x must be 16-byte aligned");
+  return run_bn_stats(x, rows, C, (float*)workspace, packed, (hipStream_t)stream);
+}
+
+int pixpro_bn_apply(const float* gathered, int32_t world, const float* x, const float* residual, const float* weight,
+                    const float* bias, float* running_mean, float* running_var, float momentum, float eps, int32_t relu,
+                    int64_t rows, int32_t C, float* y, float* mean, float* invstd, float* scale_shift, void* stream) {
+  if (!gathered || !x || !y || !mean || !invstd || !scale_shift) return bad("null pointer");
+  if (world < 1) return bad("world must be >= 1");
+  if (int e = bn_shape_ok(rows, C)) return e;
+  if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)residual | (uintptr_t)scale_shift) & 15)
+    return bad("x, y, residual, scale_shift must be 16-byte aligned");
+  return run_bn_apply(gathered, world, x, residual, weight, bias, running_mean, running_var, momentum, eps, relu, rows, C,
+                      y, mean, invstd, scale_shift, (hipStream_t)stream);
+}
+
+int pixpro_bn_backward_reduce(const float* dy, const float* x, const float* y, const float* mean, const float* invstd,
+                              int32_t relu, int64_t rows, int32_t C, void* workspace, size_t workspace_bytes,
+                              float* sums, float* grad_weight, float* grad_bias, void* stream) {
+  if (!dy || !x || !mean || !invstd || !workspace || !sums) return bad("null pointer");
+  if (relu && !y) return bad("relu backward needs the forward output y");
+  if (int e = bn_shape_ok(rows, C)) return e;
+  if (workspace_bytes < pixpro_bn_workspace_bytes(rows, C)) return bad("workspace too small");
+  if (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)y | (uintptr_t)mean) & 15) return bad("dy, x, y, mean must be 16-byte aligned");
+  return run_bn_bwd_reduce(dy, x, y, mean, invstd, relu, rows, C, (float*)workspace, sums, grad_weight, grad_bias,
+                           (hipStream_t)stream);
+}
+
+int pixpro_bn_backward_apply(const float* dy, const float* x, const float* y, const float* mean, const float* invstd,
+                             const float* weight, const float* sums, double count, int32_t relu, int64_t rows, int32_t C,
+                             float* dx, float* dresidual, void* stream) {
+  if (!dy || !x || !mean || !invstd || !sums || !dx) return bad("null pointer");
+  if (relu && !y) return bad("relu backward needs the forward output y");
+  if (!(count >= 1.0)) return bad("count must be >= 1");
+  if (int e = bn_shape_ok(rows, C)) return e;
+  if (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)y | (uintptr_t)dx | (uintptr_t)dresidual | (uintptr_t)mean |
+       (uintptr_t)invstd | (uintptr_t)weight | (uintptr_t)sums) & 15)
+    return bad("batch norm backward operands must be 16-byte aligned");
+  return run_bn_bwd_apply(dy, x, y, mean, invstd, weight, sums, count, relu, rows, C, dx, dresidual, (hipStream_t)stream);
 }
 
 }  // extern "C"

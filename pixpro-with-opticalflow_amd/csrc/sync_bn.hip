@@ -1,0 +1,319 @@
+// Training-mode (Sync)BatchNorm over NHWC fp32 activations with the ReLU and the residual add of the ResNet blocks
+// folded in.  The reference converts every BN of the encoders / projectors to
+// torch.nn.SyncBatchNorm (contrast/models/PixPro.py:289-292); with more than one rank that module leaves MIOpen and
+// runs ATen's native kernels (torch/nn/modules/_functions.py: batch_norm_stats -> all_gather ->
+// batch_norm_gather_stats_with_counts -> batch_norm_elemt; backward_reduce -> all_reduce -> backward_elemt), which
+// on MI355X cost 188 ms per N=256 step against 65 ms for MIOpen's single-rank kernels
+// (profiles/r01_syncbn_microbench.txt).  These kernels keep the same split (local statistics | exchange | apply),
+// so the collectives stay where torch has them, and stream x as [M = N*H*W rows][C] with 16 B per lane:
+//
+//   forward   k_stats (1 read of x)  -> k_stats_finalize -> [all_gather of 2C+1 floats] -> k_merge -> k_apply
+//             k_apply: y = relu?( (x-mean)*invstd*w + b (+ residual) )                      (read x [,res], write y)
+//   backward  k_bwd_reduce: dz = dy * (y > 0)?; sum dz, sum dz*(x-mean)                      (read dy, x [,y])
+//             -> k_bwd_finalize -> [all_reduce of 2C floats] -> k_bwd_apply: dx [, dres = dz] (read dy, x [,y])
+//
+// Statistics are accumulated as shifted sums (pivot = the channel's first element), so the variance does not suffer
+// the E[x^2]-E[x]^2 cancellation; partial sums are combined in a fixed order (deterministic, no atomics).
+#include <algorithm>
+
+#include "common.h"
+
+namespace pixpro {
+namespace {
+
+constexpr int BN_TPB = 256;
+
+struct BnTile {
+  int TX, TY;        // lanes along channels (float4 units) x rows per block iteration; TX * TY = 256
+  int gx, gy;        // grid: channel chunks x row blocks
+};
+
+// C4 = C/4.  TX = largest power of two <= 64 dividing C4; row blocks sized for ~4 blocks of 256 threads per CU.
+inline BnTile bn_tile(int64_t M, int C4) {
+  BnTile t;
+  t.TX = 1;
+  while (t.TX < 64 && C4 % (t.TX * 2) == 0) t.TX *= 2;
+  t.TY = BN_TPB / t.TX;
+  t.gx = C4 / t.TX;
+  int64_t want = std::max<int64_t>(1, 1024 / t.gx);
+  int64_t most = std::max<int64_t>(1, (M + (int64_t)t.TY * 4 - 1) / ((int64_t)t.TY * 4));   // >= 4 rows per thread
+  t.gy = (int)std::min<int64_t>(std::min(want, most), 65535);
+  return t;
+}
+
+__device__ __forceinline__ float4 ld4(const float* p, int64_t i4) { return reinterpret_cast<const float4*>(p)[i4]; }
+__device__ __forceinline__ void st4(float* p, int64_t i4, float4 v) { reinterpret_cast<float4*>(p)[i4] = v; }
+
+#define BN_ROWS(body)                                                                   \
+  const int tx = threadIdx.x & (TX - 1), ty = threadIdx.x / TX;                         \
+  const int c4 = blockIdx.x * TX + tx;                                                  \
+  const int64_t step = (int64_t)gridDim.y * TY;                                         \
+  int64_t r = (int64_t)blockIdx.y * TY + ty;                                            \
+  for (; r + 3 * step < M; r += 4 * step) {                                             \
+    body(r) body(r + step) body(r + 2 * step) body(r + 3 * step)                        \
+  }                                                                                     \
+  for (; r < M; r += step) { body(r) }
+
+// reduce two float4 per thread over the TY rows of the block (fixed order) -> out0/out1 of the ty == 0 lanes
+__device__ __forceinline__ void block_rows_sum(float4& a, float4& b, int TX, int TY, float4* sh) {
+  const int tx = threadIdx.x & (TX - 1), ty = threadIdx.x / TX;
+  sh[threadIdx.x] = a;
+  sh[BN_TPB + threadIdx.x] = b;
+  __syncthreads();
+  if (ty == 0) {
+    for (int k = 1; k < TY; ++k) {
+      const float4 u = sh[k * TX + tx], v = sh[BN_TPB + k * TX + tx];
+      a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+      b.x += v.x; b.y += v.y; b.z += v.z; b.w += v.w;
+    }
+  }
+}
+
+// partial[by][0][C] = sum (x - K), partial[by][1][C] = sum (x - K)^2,  K = x[0][c]
+__global__ void __launch_bounds__(BN_TPB)
+k_stats(const float* __restrict__ x, float* __restrict__ partial, int64_t M, int C4, int TX, int TY) {
+  __shared__ float4 sh[2 * BN_TPB];
+  float4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
+  const float4 K = ld4(x, blockIdx.x * TX + (threadIdx.x & (TX - 1)));
+#define BODY(row) { const float4 v = ld4(x, (row) * C4 + c4);                                                  \
+    const float dx_ = v.x - K.x, dy_ = v.y - K.y, dz_ = v.z - K.z, dw_ = v.w - K.w;                            \
+    s.x += dx_; s.y += dy_; s.z += dz_; s.w += dw_;                                                           \
+    q.x = __builtin_fmaf(dx_, dx_, q.x); q.y = __builtin_fmaf(dy_, dy_, q.y);                                  \
+    q.z = __builtin_fmaf(dz_, dz_, q.z); q.w = __builtin_fmaf(dw_, dw_, q.w); }
+  BN_ROWS(BODY)
+#undef BODY
+  block_rows_sum(s, q, TX, TY, sh);
+  if (ty == 0) {
+    const int64_t C = (int64_t)C4 * 4;
+    float* p = partial + (int64_t)blockIdx.y * 2 * C;
+    st4(p, c4, s);
+    st4(p + C, c4, q);
+  }
+}
+
+// Column sums of the [nblk][2][C] partials: 8 channels x 32 row groups per block, double accumulation (the partials are
+// long sums themselves), fixed order.  Returns the two totals of channel c in the g == 0 lanes.
+constexpr int FIN_CH = 8, FIN_G = BN_TPB / FIN_CH;
+__device__ __forceinline__ bool finalize_sums(const float* __restrict__ partial, int nblk, int C, int& c, double& s,
+                                              double& q) {
+  __shared__ double red[2][FIN_G][FIN_CH];
+  const int lc = threadIdx.x % FIN_CH, g = threadIdx.x / FIN_CH;
+  c = blockIdx.x * FIN_CH + lc;
+  s = 0.0; q = 0.0;
+  if (c < C)
+    for (int b = g; b < nblk; b += FIN_G) {
+      s += (double)partial[(int64_t)b * 2 * C + c];
+      q += (double)partial[(int64_t)b * 2 * C + C + c];
+    }
+  red[0][g][lc] = s;
+  red[1][g][lc] = q;
+  __syncthreads();
+  if (g != 0 || c >= C) return false;
+  for (int k = 1; k < FIN_G; ++k) { s += red[0][k][lc]; q += red[1][k][lc]; }
+  return true;
+}
+
+// packed[0..C) = mean, packed[C..2C) = biased variance, packed[2C] = M     (what one rank contributes)
+__global__ void __launch_bounds__(BN_TPB)
+k_stats_finalize(const float* __restrict__ x, const float* __restrict__ partial, int nblk, int64_t M, int C,
+                 float* __restrict__ packed) {
+  int c;
+  double s, q;
+  if (!finalize_sums(partial, nblk, C, c, s, q)) return;
+  const double n = (double)M;
+  const double ms = s / n;
+  packed[c] = (float)((double)x[c] + ms);
+  packed[C + c] = (float)fmax(q / n - ms * ms, 0.0);
+  if (c == 0) packed[2 * C] = (float)M;
+}
+
+// gathered [W][2C+1] -> mean, invstd (saved for backward), scale/shift for k_apply, running statistics
+// (batch_norm_gather_stats_with_counts: count-weighted merge; running_var takes the unbiased variance)
+__global__ void k_merge(const float* __restrict__ gathered, int W, int C, const float* __restrict__ weight,
+                        const float* __restrict__ bias, float* __restrict__ running_mean, float* __restrict__ running_var,
+                        float momentum, float eps, float* __restrict__ mean_out, float* __restrict__ invstd_out,
+                        float* __restrict__ scale_shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const int64_t S = 2 * (int64_t)C + 1;
+  double n = 0.0, md = 0.0;
+  for (int r = 0; r < W; ++r) {
+    const double nr = (double)gathered[r * S + 2 * C];
+    n += nr;
+    md += nr * (double)gathered[r * S + c];
+  }
+  md = md / n;
+  double v = 0.0;
+  for (int r = 0; r < W; ++r) {
+    const double nr = (double)gathered[r * S + 2 * C], d = (double)gathered[r * S + c] - md;
+    v += nr * ((double)gathered[r * S + C + c] + d * d);
+  }
+  const float m = (float)md;
+  const float var = (float)(v / n);
+  const float invstd = 1.f / sqrtf(var + eps);
+  mean_out[c] = m;
+  invstd_out[c] = invstd;
+  const float sc = (weight ? weight[c] : 1.f) * invstd;
+  scale_shift[c] = sc;
+  scale_shift[C + c] = (bias ? bias[c] : 0.f) - m * sc;
+  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
+  if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(v / fmax(n - 1.0, 1.0));
+}
+
+template <bool RELU, bool RES>
+__global__ void __launch_bounds__(BN_TPB)
+k_apply(const float* __restrict__ x, const float* __restrict__ res, const float* __restrict__ scale_shift,
+        float* __restrict__ y, int64_t M, int C4, int TX, int TY) {
+  const int cc = blockIdx.x * TX + (threadIdx.x & (TX - 1));
+  const float4 sc = ld4(scale_shift, cc), sf = ld4(scale_shift + (int64_t)C4 * 4, cc);
+#define BODY(row) { const int64_t i = (row) * C4 + c4; const float4 v = ld4(x, i); float4 o;                   \
+    o.x = __builtin_fmaf(v.x, sc.x, sf.x); o.y = __builtin_fmaf(v.y, sc.y, sf.y);                              \
+    o.z = __builtin_fmaf(v.z, sc.z, sf.z); o.w = __builtin_fmaf(v.w, sc.w, sf.w);                              \
+    if (RES) { const float4 e = ld4(res, i); o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w; }                 \
+    if (RELU) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }  \
+    st4(y, i, o); }
+  BN_ROWS(BODY)
+#undef BODY
+}
+
+// partial[by][0][C] = sum dz, partial[by][1][C] = sum dz * (x - mean);  dz = dy masked by y > 0 when RELU
+template <bool RELU>
+__global__ void __launch_bounds__(BN_TPB)
+k_bwd_reduce(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ y,
+             const float* __restrict__ mean, float* __restrict__ partial, int64_t M, int C4, int TX, int TY) {
+  __shared__ float4 sh[2 * BN_TPB];
+  float4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
+  const float4 mu = ld4(mean, blockIdx.x * TX + (threadIdx.x & (TX - 1)));
+#define BODY(row) { const int64_t i = (row) * C4 + c4; float4 g = ld4(dy, i); const float4 v = ld4(x, i);       \
+    if (RELU) { const float4 o = ld4(y, i); g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f;           \
+                g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f; }                                    \
+    s.x += g.x; s.y += g.y; s.z += g.z; s.w += g.w;                                                            \
+    q.x = __builtin_fmaf(g.x, v.x - mu.x, q.x); q.y = __builtin_fmaf(g.y, v.y - mu.y, q.y);                    \
+    q.z = __builtin_fmaf(g.z, v.z - mu.z, q.z); q.w = __builtin_fmaf(g.w, v.w - mu.w, q.w); }
+  BN_ROWS(BODY)
+#undef BODY
+  block_rows_sum(s, q, TX, TY, sh);
+  if (ty == 0) {
+    const int64_t C = (int64_t)C4 * 4;
+    float* p = partial + (int64_t)blockIdx.y * 2 * C;
+    st4(p, c4, s);
+    st4(p + C, c4, q);
+  }
+}
+
+// sums[0..C) = sum dz, sums[C..2C) = sum dz (x - mean)   (this rank); grad_weight = sums[C+c] * invstd, grad_bias
+__global__ void __launch_bounds__(BN_TPB)
+k_bwd_finalize(const float* __restrict__ partial, int nblk, int C, const float* __restrict__ invstd,
+               float* __restrict__ sums, float* __restrict__ grad_weight, float* __restrict__ grad_bias) {
+  int c;
+  double sd, qd;
+  if (!finalize_sums(partial, nblk, C, c, sd, qd)) return;
+  const float s = (float)sd, q = (float)qd;
+  sums[c] = s;
+  sums[C + c] = q;
+  if (grad_weight) grad_weight[c] = q * invstd[c];
+  if (grad_bias) grad_bias[c] = s;
+}
+
+// dx = (dz - sum_dz/n - (x - mean) * invstd^2 * sum_dz_xmu/n) * invstd * w        (batch_norm_backward_elemt)
+template <bool RELU, bool RES>
+__global__ void __launch_bounds__(BN_TPB)
+k_bwd_apply(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ y,
+            const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ weight,
+            const float* __restrict__ sums, float inv_n, float* __restrict__ dx, float* __restrict__ dres, int64_t M,
+            int C4, int TX, int TY) {
+  const int cc = blockIdx.x * TX + (threadIdx.x & (TX - 1));
+  const int64_t C = (int64_t)C4 * 4;
+  const float4 mu = ld4(mean, cc), is = ld4(invstd, cc);
+  const float4 w = weight ? ld4(weight, cc) : make_float4(1.f, 1.f, 1.f, 1.f);
+  const float4 sd = ld4(sums, cc), sx = ld4(sums + C, cc);
+  // dx = dz * a + (x - mean) * b + c  per channel
+  float4 a, b, c;
+  a.x = is.x * w.x; a.y = is.y * w.y; a.z = is.z * w.z; a.w = is.w * w.w;
+  b.x = -(sx.x * inv_n) * is.x * is.x * a.x; b.y = -(sx.y * inv_n) * is.y * is.y * a.y;
+  b.z = -(sx.z * inv_n) * is.z * is.z * a.z; b.w = -(sx.w * inv_n) * is.w * is.w * a.w;
+  c.x = -(sd.x * inv_n) * a.x; c.y = -(sd.y * inv_n) * a.y; c.z = -(sd.z * inv_n) * a.z; c.w = -(sd.w * inv_n) * a.w;
+#define BODY(row) { const int64_t i = (row) * C4 + c4; float4 g = ld4(dy, i); const float4 v = ld4(x, i);       \
+    if (RELU) { const float4 o = ld4(y, i); g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f;           \
+                g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f; }                                    \
+    if (RES) st4(dres, i, g);                                                                                 \
+    float4 o2;                                                                                                \
+    o2.x = __builtin_fmaf(g.x, a.x, __builtin_fmaf(v.x - mu.x, b.x, c.x));                                    \
+    o2.y = __builtin_fmaf(g.y, a.y, __builtin_fmaf(v.y - mu.y, b.y, c.y));                                    \
+    o2.z = __builtin_fmaf(g.z, a.z, __builtin_fmaf(v.z - mu.z, b.z, c.z));                                    \
+    o2.w = __builtin_fmaf(g.w, a.w, __builtin_fmaf(v.w - mu.w, b.w, c.w));                                    \
+    st4(dx, i, o2); }
+  BN_ROWS(BODY)
+#undef BODY
+}
+
+#define CHECKED(what)                         \
+  do {                                        \
+    if (int e = check_launch(what)) return e; \
+  } while (0)
+
+}  // namespace
+
+size_t bn_workspace_floats(int64_t M, int C) {
+  const BnTile t = bn_tile(M, C / 4);
+  return (size_t)t.gy * 2 * C;
+}
+
+int run_bn_stats(const float* x, int64_t M, int C, float* ws, float* packed, hipStream_t st) {
+  const BnTile t = bn_tile(M, C / 4);
+  hipLaunchKernelGGL(k_stats, dim3(t.gx, t.gy), dim3(BN_TPB), 0, st, x, ws, M, C / 4, t.TX, t.TY);
+  CHECKED("k_stats");
+  hipLaunchKernelGGL(k_stats_finalize, dim3((C + FIN_CH - 1) / FIN_CH), dim3(BN_TPB), 0, st, x, ws, t.gy, M, C, packed);
+  CHECKED("k_stats_finalize");
+  return PIXPRO_OK;
+}
+
+int run_bn_apply(const float* gathered, int W, const float* x, const float* res, const float* weight, const float* bias,
+                 float* running_mean, float* running_var, float momentum, float eps, int relu, int64_t M, int C,
+                 float* y, float* mean, float* invstd, float* scale_shift, hipStream_t st) {
+  hipLaunchKernelGGL(k_merge, dim3((C + 255) / 256), dim3(256), 0, st, gathered, W, C, weight, bias, running_mean,
+                     running_var, momentum, eps, mean, invstd, scale_shift);
+  CHECKED("k_merge");
+  const BnTile t = bn_tile(M, C / 4);
+  const dim3 g(t.gx, t.gy), b(BN_TPB);
+#define APPLY(R, S) hipLaunchKernelGGL((k_apply<R, S>), g, b, 0, st, x, res, scale_shift, y, M, C / 4, t.TX, t.TY)
+  if (relu && res) APPLY(true, true);
+  else if (relu) APPLY(true, false);
+  else if (res) APPLY(false, true);
+  else APPLY(false, false);
+#undef APPLY
+  CHECKED("k_apply");
+  return PIXPRO_OK;
+}
+
+int run_bn_bwd_reduce(const float* dy, const float* x, const float* y, const float* mean, const float* invstd, int relu,
+                      int64_t M, int C, float* ws, float* sums, float* grad_weight, float* grad_bias, hipStream_t st) {
+  const BnTile t = bn_tile(M, C / 4);
+  const dim3 g(t.gx, t.gy), b(BN_TPB);
+  if (relu) hipLaunchKernelGGL((k_bwd_reduce<true>), g, b, 0, st, dy, x, y, mean, ws, M, C / 4, t.TX, t.TY);
+  else hipLaunchKernelGGL((k_bwd_reduce<false>), g, b, 0, st, dy, x, y, mean, ws, M, C / 4, t.TX, t.TY);
+  CHECKED("k_bwd_reduce");
+  hipLaunchKernelGGL(k_bwd_finalize, dim3((C + FIN_CH - 1) / FIN_CH), dim3(BN_TPB), 0, st, ws, t.gy, C, invstd, sums, grad_weight,
+                     grad_bias);
+  CHECKED("k_bwd_finalize");
+  return PIXPRO_OK;
+}
+
+int run_bn_bwd_apply(const float* dy, const float* x, const float* y, const float* mean, const float* invstd,
+                     const float* weight, const float* sums, double count, int relu, int64_t M, int C, float* dx,
+                     float* dres, hipStream_t st) {
+  const BnTile t = bn_tile(M, C / 4);
+  const dim3 g(t.gx, t.gy), b(BN_TPB);
+  const float inv_n = (float)(1.0 / count);
+#define BAPPLY(R, S) hipLaunchKernelGGL((k_bwd_apply<R, S>), g, b, 0, st, dy, x, y, mean, invstd, weight, sums, inv_n, \
+                                        dx, dres, M, C / 4, t.TX, t.TY)
+  if (relu && dres) BAPPLY(true, true);
+  else if (relu) BAPPLY(true, false);
+  else if (dres) BAPPLY(false, true);
+  else BAPPLY(false, false);
+#undef BAPPLY
+  CHECKED("k_bwd_apply");
+  return PIXPRO_OK;
+}
+
+}  // namespace pixpro

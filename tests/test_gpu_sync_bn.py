@@ -1,0 +1,199 @@
+"""FusedSyncBatchNorm (csrc/sync_bn.hip through the C ABI) against torch's own batch norm + add + ReLU in fp32:
+forward, all gradients, running statistics, two gloo ranks sharing the GPU against one process on the whole batch,
+and the PixPro model with / without the fused modules.  Tolerances: outputs 2e-5 abs (values are O(1)), gradients
+1e-4 of the reference's max-abs, statistics 1e-5 relative."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+import torch.nn.functional as F
+
+from conftest import PKG, ROOT
+from gpu_utils import close
+
+pytestmark = pytest.mark.gpu
+CL = torch.channels_last
+
+
+def _reference(x, w, b, res, relu, rm, rv, momentum=0.1, eps=1e-5):
+    """torch's batch norm + add + ReLU.  Double inputs give the exact-arithmetic reference (MIOpen's fp32 kernels lose
+    digits of the variance when a channel holds a handful of nearly equal values, e.g. N=2 at 1x1)."""
+    y = F.batch_norm(x, rm, rv, w, b, True, momentum, eps)
+    if res is not None:
+        y = y + res
+    if relu is True:
+        return F.relu(y)
+    # a mask instead of True: the ReLU decisions of the implementation under test (an output within rounding of zero may
+    # sit on either side; with ~10^2 values per channel one flipped decision moves that channel's sums visibly)
+    return y * relu.to(y.dtype) if isinstance(relu, torch.Tensor) else y
+
+
+@pytest.mark.parametrize("shape", [(8, 64, 14, 14), (4, 256, 7, 7), (3, 2048, 7, 7), (16, 64, 56, 56), (32, 4096, 1, 1),
+                                   (5, 36, 9, 11), (2, 1024, 14, 14), (64, 4, 3, 3)])
+@pytest.mark.parametrize("relu,with_res", [(False, False), (True, False), (True, True), (False, True)])
+def test_forward_backward_match_torch(dev, shape, relu, with_res):
+    from contrast.sync_bn import FusedSyncBatchNorm
+    g = torch.Generator().manual_seed(sum(shape) + 2 * relu + with_res)
+    N, C, H, W = shape
+    x = (torch.randn(shape, generator=g) * 1.7 + 0.4).to(dev).contiguous(memory_format=CL)
+    res = torch.randn(shape, generator=g).to(dev).contiguous(memory_format=CL) if with_res else None
+    dy = torch.randn(shape, generator=g).to(dev).contiguous(memory_format=CL)
+    bn = FusedSyncBatchNorm(C).to(dev).train()
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(C, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(C, generator=g) * 0.3)
+    rm, rv = bn.running_mean.double(), bn.running_var.double()
+    w0, b0 = bn.weight.detach().double().requires_grad_(True), bn.bias.detach().double().requires_grad_(True)
+    xr = x.double().requires_grad_(True)
+    rr = res.double().requires_grad_(True) if with_res else None
+    xf = x.clone().requires_grad_(True)
+    rf = res.clone().requires_grad_(True) if with_res else None
+    got = bn(xf, rf, relu)
+    got.backward(dy)
+    want = _reference(xr, w0, b0, rr, (got > 0) if relu else False, rm, rv)
+    want.backward(dy.double())
+    assert got.is_contiguous(memory_format=CL) and got.shape == x.shape
+    assert (got - want).abs().max().item() <= 2e-5
+    close(xf.grad, xr.grad)
+    close(bn.weight.grad, w0.grad, rel=2e-4)
+    close(bn.bias.grad, b0.grad, rel=2e-4)
+    if with_res:
+        close(rf.grad, rr.grad)
+    assert torch.allclose(bn.running_mean.double(), rm, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(bn.running_var.double(), rv, rtol=1e-5, atol=1e-6)
+    assert int(bn.num_batches_tracked) == 1
+
+
+def test_statistics_survive_a_large_mean(dev):
+    """Shifted sums: a channel mean 1000x its standard deviation must not destroy the variance."""
+    from contrast.sync_bn import FusedSyncBatchNorm
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(32, 64, 28, 28, generator=g) * 0.05 + 50.0).to(dev).contiguous(memory_format=CL)
+    bn = FusedSyncBatchNorm(64).to(dev).train()
+    y = bn(x)
+    x64 = x.double()
+    mu = x64.mean((0, 2, 3), keepdim=True)
+    var = x64.var((0, 2, 3), unbiased=False, keepdim=True)
+    want = ((x64 - mu) / torch.sqrt(var + 1e-5)).float()
+    assert (y - want).abs().max().item() <= 2e-3          # fp32 input rounding at |x| = 50 is 4e-6 / 0.05 std already
+    assert torch.allclose(bn.running_var, (0.9 + 0.1 * x64.var((0, 2, 3))).float(), rtol=1e-4)
+
+
+def test_eval_mode_and_errors(dev):
+    from contrast.sync_bn import FusedSyncBatchNorm
+    bn = FusedSyncBatchNorm(8).to(dev)
+    x = torch.randn(4, 8, 5, 5, device=dev).contiguous(memory_format=CL)
+    bn.train()
+    bn(x)
+    bn.eval()
+    want = F.relu(F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, False, 0.0, 1e-5) + x)
+    assert torch.allclose(bn(x, x, True), want)
+    bn.train()
+    with pytest.raises(RuntimeError):
+        bn(x.cpu())
+    with pytest.raises(RuntimeError):
+        FusedSyncBatchNorm(6).to(dev).train()(torch.randn(2, 6, 3, 3, device=dev))   # C not a multiple of 4
+    nchw = torch.randn(4, 8, 5, 5, device=dev)
+    assert torch.allclose(bn(nchw), bn(nchw.contiguous(memory_format=CL)), atol=1e-6)  # converted, not rejected
+
+
+def test_convert_shares_parameters_and_names(dev):
+    from contrast import resnet
+    from contrast.sync_bn import FusedSyncBatchNorm
+    plain = resnet.resnet18(head_type="early_return")
+    names = list(plain.state_dict().keys())
+    fused = FusedSyncBatchNorm.convert(plain)
+    assert list(fused.state_dict().keys()) == names
+    assert all(not (isinstance(m, nn.BatchNorm2d) and not isinstance(m, FusedSyncBatchNorm)) for m in fused.modules())
+    assert sum(isinstance(m, FusedSyncBatchNorm) for m in fused.modules()) == 20
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _rank(rank, world, port, path):
+    for p in (ROOT, PKG):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from contrast.sync_bn import FusedSyncBatchNorm
+    dev = torch.device("cuda:0")
+    d = torch.load(path)
+    n = d["x"].shape[0] // world
+    sl = slice(rank * n, (rank + 1) * n)
+    bn = FusedSyncBatchNorm(d["x"].shape[1]).to(dev).train()
+    with torch.no_grad():
+        bn.weight.copy_(d["w"]); bn.bias.copy_(d["b"])
+    x = d["x"][sl].to(dev).contiguous(memory_format=CL).requires_grad_(True)
+    res = d["res"][sl].to(dev).contiguous(memory_format=CL).requires_grad_(True)
+    y = bn(x, res, True)
+    y.backward(d["dy"][sl].to(dev).contiguous(memory_format=CL))
+    torch.save(dict(y=y.detach().cpu(), dx=x.grad.cpu(), dres=res.grad.cpu(), dw=bn.weight.grad.cpu(), db=bn.bias.grad.cpu(),
+                    rm=bn.running_mean.cpu(), rv=bn.running_var.cpu()), f"{path}.out{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_equal_one_process_on_the_whole_batch(dev, tmp_path):
+    """The SyncBN contract: statistics and input gradients are those of the global batch; parameter gradients are the
+    local sums (DDP averages them afterwards)."""
+    g = torch.Generator().manual_seed(11)
+    shape = (12, 128, 9, 9)
+    d = dict(x=torch.randn(shape, generator=g) * 2 + 1, res=torch.randn(shape, generator=g), dy=torch.randn(shape, generator=g),
+             w=torch.rand(128, generator=g) + 0.5, b=torch.randn(128, generator=g))
+    d["x"][6:] += 0.7                                   # the two shards have different statistics
+    path = str(tmp_path / "case.pt")
+    torch.save(d, path)
+    mp.spawn(_rank, args=(2, _free_port(), path), nprocs=2, join=True)
+    outs = [torch.load(f"{path}.out{r}") for r in range(2)]
+    x = d["x"].to(dev).contiguous(memory_format=CL).requires_grad_(True)
+    res = d["res"].to(dev).contiguous(memory_format=CL).requires_grad_(True)
+    w, b = d["w"].to(dev).requires_grad_(True), d["b"].to(dev).requires_grad_(True)
+    rm, rv = torch.zeros(128, device=dev), torch.ones(128, device=dev)
+    y = torch.cat([o["y"] for o in outs]).to(dev)
+    want = _reference(x, w, b, res, y > 0, rm, rv)
+    want.backward(d["dy"].to(dev).contiguous(memory_format=CL))
+    assert (y - want).abs().max().item() <= 2e-5
+    close(torch.cat([o["dx"] for o in outs]).to(dev), x.grad)
+    close(torch.cat([o["dres"] for o in outs]).to(dev), res.grad)
+    close(outs[0]["dw"] + outs[1]["dw"], w.grad, rel=2e-4)
+    close(outs[0]["db"] + outs[1]["db"], b.grad, rel=2e-4)
+    for o in outs:
+        assert torch.allclose(o["rm"].to(dev), rm, rtol=1e-5, atol=1e-6) and torch.allclose(o["rv"].to(dev), rv, rtol=1e-5, atol=1e-6)
+
+
+def test_model_step_with_fused_bn_matches_stock(dev):
+    """ResNet-18 PixPro step (cfg-1 shapes), same weights and inputs, stock BatchNorm + ReLU vs the fused modules."""
+    import types
+    import importlib
+    pixpro_mod = importlib.import_module("contrast.models.PixPro")
+    from contrast import resnet
+    from contrast.synthetic import make_batch
+    out = []
+    for fused in (False, True):
+        torch.manual_seed(0)
+        margs = types.SimpleNamespace(pixpro_p=2.0, pixpro_momentum=0.99, pixpro_pos_ratio=0.7, pixpro_clamp_value=0.0,
+                                      pixpro_transform_layer=1, pixpro_ins_loss_weight=0.0, output_dir="/tmp",
+                                      num_instances=70000, batch_size=8, epochs=2000, start_epoch=1, feature_dim=256,
+                                      head_type="early_return", sync_bn=True, fused_bn=fused)
+        model = pixpro_mod.PixPro(resnet.resnet18, margs).to(dev).to(memory_format=CL).train()
+        d = make_batch(8, image_size=64, n_frames=2, frame_hw=(180, 320), device=dev, seed=7, with_flow=False)
+        im1, im2 = d[0].contiguous(memory_format=CL), d[1].contiguous(memory_format=CL)
+        loss, (a, b) = model(im1, im2, d[2], d[3])
+        loss.backward()
+        out.append((loss.item(), a[0].clone(), model.encoder.conv1.weight.grad.clone(),
+                    model.projector.linear2.weight.grad.clone(), model.encoder.bn1.running_var.clone()))
+    assert abs(out[0][0] - out[1][0]) <= 1e-5 and torch.equal(out[0][1], out[1][1])
+    close(out[1][3], out[0][3], rel=2e-3)
+    close(out[1][2], out[0][2], rel=3e-2)       # 53 normalisations deep; re-association noise amplified by BN at 32 values
+    assert torch.allclose(out[0][4], out[1][4], rtol=1e-4)

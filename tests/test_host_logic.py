@@ -139,3 +139,23 @@ def test_lars_grouping():
     g = add_weight_decay(net, 1e-5)
     assert [len(x["params"]) for x in g] == [3, 1] and g[0]["ignore"] and not g[1]["ignore"]
     assert g[0]["weight_decay"] == 0 and g[1]["weight_decay"] == 1e-5
+
+
+def test_fused_bn_conversion_keeps_names_and_has_no_cpu_route():
+    import torch.nn as nn
+    from contrast import resnet
+    from contrast.sync_bn import FusedSyncBatchNorm, bn_act
+    plain = resnet.resnet18(head_type="early_return")
+    names = list(plain.state_dict().keys())
+    w = plain.bn1.weight
+    fused = FusedSyncBatchNorm.convert(plain)
+    assert list(fused.state_dict().keys()) == names and fused.bn1.weight is w
+    assert isinstance(fused.layer1[0].bn2, FusedSyncBatchNorm) and isinstance(fused.layer2[0].downsample[1], FusedSyncBatchNorm)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        fused.train()(torch.randn(2, 3, 32, 32))
+    # eval mode needs no statistics kernel and runs anywhere; stock modules go through the stock ops
+    fused.eval()
+    assert fused(torch.randn(1, 3, 32, 32)).shape == (1, 512, 1, 1)
+    bn = nn.BatchNorm2d(4)
+    x, r = torch.randn(2, 4, 3, 3), torch.randn(2, 4, 3, 3)
+    assert torch.equal(bn_act(bn, x, relu=True, residual=r), torch.relu(bn(x) + r))
