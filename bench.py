@@ -57,8 +57,9 @@ def parse():
     ap.add_argument("--lazy-flow", action="store_true",
                     help="skip the dense flow preparation, evaluate flow chain + mask inside the loss kernel "
                          "(same results; the default keeps the reference's dense pipeline, which BASELINE's metric names)")
-    ap.add_argument("--fused-bn", action="store_true",
-                    help="HIP (Sync)BatchNorm with ReLU / residual add folded in instead of torch's (Sync)BatchNorm + ReLU")
+    ap.add_argument("--no-fused-bn", dest="fused_bn", action="store_false",
+                    help="torch's (Sync)BatchNorm + ReLU + add instead of the HIP (Sync)BatchNorm with ReLU / residual add "
+                         "folded in (default: fused; same statistics exchange, tests/test_gpu_sync_bn.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-flow-images", type=int, default=8)
     ap.add_argument("--no-channels-last", dest="channels_last", action="store_false",

@@ -198,15 +198,17 @@ int pixpro_bn_apply(const float* gathered, int32_t world, const float* x, const 
                     float momentum, float eps, int32_t relu, int64_t rows, int32_t C, float* y,
                     float* mean, float* invstd, float* scale_shift, void* stream);
 /* dz = dy * (y > 0) if relu else dy.  sums[0..C) = sum dz, sums[C..2C) = sum dz*(x-mean) of this rank;
- * grad_weight = sums[C..2C) * invstd, grad_bias = sums[0..C) (nullable). */
-int pixpro_bn_backward_reduce(const float* dy, const float* x, const float* y, const float* mean,
-                              const float* invstd, int32_t relu, int64_t rows, int32_t C,
+ * grad_weight = sums[C..2C) * invstd, grad_bias = sums[0..C) (nullable).
+ * The ReLU decision is read from the saved output y, or - when the forward had no residual - recomputed from x with the
+ * forward's scale_shift (pass it and y may be NULL: one tensor read less). */
+int pixpro_bn_backward_reduce(const float* dy, const float* x, const float* y, const float* scale_shift,
+                              const float* mean, const float* invstd, int32_t relu, int64_t rows, int32_t C,
                               void* workspace, size_t workspace_bytes, float* sums,
                               float* grad_weight, float* grad_bias, void* stream);
 /* sums: totals over all ranks, count: total rows over all ranks.
  * dx = (dz - sum_dz/count - (x-mean)*invstd^2*sum_dz_xmu/count) * invstd * weight;  dresidual = dz (nullable). */
-int pixpro_bn_backward_apply(const float* dy, const float* x, const float* y, const float* mean,
-                             const float* invstd, const float* weight, const float* sums, double count,
+int pixpro_bn_backward_apply(const float* dy, const float* x, const float* y, const float* scale_shift,
+                             const float* mean, const float* invstd, const float* weight, const float* sums, double count,
                              int32_t relu, int64_t rows, int32_t C, float* dx, float* dresidual,
                              void* stream);
 

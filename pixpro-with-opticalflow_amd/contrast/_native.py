@@ -64,10 +64,10 @@ SIGNATURES = {
     "pixpro_bn_stats": (ctypes.c_int, [_vp, _i64, _i32, _vp, _sz, _vp, _vp]),
     "pixpro_bn_apply": (ctypes.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _i32, _i64, _i32,
                                        _vp, _vp, _vp, _vp, _vp]),
-    "pixpro_bn_backward_reduce": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _vp, _sz, _vp, _vp, _vp,
-                                                 _vp]),
-    "pixpro_bn_backward_apply": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _i32, _i64, _i32, _vp, _vp,
-                                                _vp]),
+    "pixpro_bn_backward_reduce": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _vp, _sz, _vp, _vp,
+                                                 _vp, _vp]),
+    "pixpro_bn_backward_apply": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _i32, _i64, _i32, _vp,
+                                                _vp, _vp]),
 }
 
 _lib = None

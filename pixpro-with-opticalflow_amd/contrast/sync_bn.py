@@ -77,13 +77,15 @@ class _FusedBN(torch.autograd.Function):
         nv.call("pixpro_bn_apply", nv.ptr(gathered), world, nv.ptr(x), nv.ptr(residual), nv.ptr(weight), nv.ptr(bias),
                 nv.ptr(running_mean), nv.ptr(running_var), float(momentum), float(eps), int(relu), rows, C, nv.ptr(y),
                 nv.ptr(mean), nv.ptr(invstd), nv.ptr(scale_shift), nv.stream())
-        ctx.save_for_backward(x, y if relu else None, weight, mean, invstd)
+        # the ReLU decision is recomputed from x in backward unless a residual entered it (then the output is needed)
+        ctx.save_for_backward(x, y if (relu and residual is not None) else None, weight, mean, invstd,
+                              scale_shift if (relu and residual is None) else None)
         ctx.meta = (rows, C, bool(relu), residual is not None, group, world)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, y, weight, mean, invstd = ctx.saved_tensors
+        x, y, weight, mean, invstd, scale_shift = ctx.saved_tensors
         rows, C, relu, has_res, group, world = ctx.meta
         if dy.dim() == 4 and not dy.is_contiguous(memory_format=torch.channels_last) or dy.dim() == 2 and not dy.is_contiguous():
             dy = dy.contiguous(memory_format=torch.channels_last) if dy.dim() == 4 else dy.contiguous()
@@ -96,7 +98,8 @@ class _FusedBN(torch.autograd.Function):
         need_b = ctx.needs_input_grad[2]
         gw = torch.empty(C, **f32) if need_w else None
         gb = torch.empty(C, **f32) if need_b else None
-        nv.call("pixpro_bn_backward_reduce", nv.ptr(dy), nv.ptr(x), nv.ptr(y), nv.ptr(mean), nv.ptr(invstd), int(relu),
+        nv.call("pixpro_bn_backward_reduce", nv.ptr(dy), nv.ptr(x), nv.ptr(y), nv.ptr(scale_shift), nv.ptr(mean),
+                nv.ptr(invstd), int(relu),
                 rows, C, nv.ptr(ws), wsb, nv.ptr(sums), nv.ptr(gw), nv.ptr(gb), nv.stream())
         if world > 1:
             dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
@@ -106,8 +109,8 @@ class _FusedBN(torch.autograd.Function):
             dx = torch.empty_like(x)
         if dx is not None:
             # per-rank batches are equal (the reference's loader drops the last partial batch), so count = world * rows
-            nv.call("pixpro_bn_backward_apply", nv.ptr(dy), nv.ptr(x), nv.ptr(y), nv.ptr(mean), nv.ptr(invstd),
-                    nv.ptr(weight), nv.ptr(sums), float(rows) * world, int(relu), rows, C, nv.ptr(dx), nv.ptr(dres),
+            nv.call("pixpro_bn_backward_apply", nv.ptr(dy), nv.ptr(x), nv.ptr(y), nv.ptr(scale_shift), nv.ptr(mean),
+                    nv.ptr(invstd), nv.ptr(weight), nv.ptr(sums), float(rows) * world, int(relu), rows, C, nv.ptr(dx), nv.ptr(dres),
                     nv.stream())
         return dx, gw, gb, dres, None, None, None, None, None, None
 

@@ -72,11 +72,12 @@ int run_bn_stats(const float* x, int64_t M, int C, float* ws, float* packed, hip
 int run_bn_apply(const float* gathered, int W, const float* x, const float* res, const float* weight, const float* bias,
                  float* running_mean, float* running_var, float momentum, float eps, int relu, int64_t M, int C,
                  float* y, float* mean, float* invstd, float* scale_shift, hipStream_t st);
-int run_bn_bwd_reduce(const float* dy, const float* x, const float* y, const float* mean, const float* invstd, int relu,
-                      int64_t M, int C, float* ws, float* sums, float* grad_weight, float* grad_bias, hipStream_t st);
-int run_bn_bwd_apply(const float* dy, const float* x, const float* y, const float* mean, const float* invstd,
-                     const float* weight, const float* sums, double count, int relu, int64_t M, int C, float* dx,
-                     float* dres, hipStream_t st);
+int run_bn_bwd_reduce(const float* dy, const float* x, const float* y, const float* scale_shift, const float* mean,
+                      const float* invstd, int relu, int64_t M, int C, float* ws, float* sums, float* grad_weight,
+                      float* grad_bias, hipStream_t st);
+int run_bn_bwd_apply(const float* dy, const float* x, const float* y, const float* scale_shift, const float* mean,
+                     const float* invstd, const float* weight, const float* sums, double count, int relu, int64_t M, int C,
+                     float* dx, float* dres, hipStream_t st);
 
 namespace {
 
@@ -290,29 +291,33 @@ int pixpro_bn_apply(const float* gathered, int32_t world, const float* x, const 
                       y, mean, invstd, scale_shift, (hipStream_t)stream);
 }
 
-int pixpro_bn_backward_reduce(const float* dy, const float* x, const float* y, const float* mean, const float* invstd,
-                              int32_t relu, int64_t rows, int32_t C, void* workspace, size_t workspace_bytes,
-                              float* sums, float* grad_weight, float* grad_bias, void* stream) {
+int pixpro_bn_backward_reduce(const float* dy, const float* x, const float* y, const float* scale_shift,
+                              const float* mean, const float* invstd, int32_t relu, int64_t rows, int32_t C,
+                              void* workspace, size_t workspace_bytes, float* sums, float* grad_weight,
+                              float* grad_bias, void* stream) {
   if (!dy || !x || !mean || !invstd || !workspace || !sums) return bad("null pointer");
-  if (relu && !y) return bad("relu backward needs the forward output y");
+  if (relu && !y && !scale_shift) return bad("relu backward needs the forward output y or the forward's scale_shift");
+  if ((uintptr_t)scale_shift & 15) return bad("scale_shift must be 16-byte aligned");
   if (int e = bn_shape_ok(rows, C)) return e;
   if (workspace_bytes < pixpro_bn_workspace_bytes(rows, C)) return bad("workspace too small");
   if (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)y | (uintptr_t)mean) & 15) return bad("dy, x, y, mean must be 16-byte aligned");
-  return run_bn_bwd_reduce(dy, x, y, mean, invstd, relu, rows, C, (float*)workspace, sums, grad_weight, grad_bias,
-                           (hipStream_t)stream);
+  return run_bn_bwd_reduce(dy, x, y, scale_shift, mean, invstd, relu, rows, C, (float*)workspace, sums, grad_weight,
+                           grad_bias, (hipStream_t)stream);
 }
 
-int pixpro_bn_backward_apply(const float* dy, const float* x, const float* y, const float* mean, const float* invstd,
-                             const float* weight, const float* sums, double count, int32_t relu, int64_t rows, int32_t C,
-                             float* dx, float* dresidual, void* stream) {
+int pixpro_bn_backward_apply(const float* dy, const float* x, const float* y, const float* scale_shift,
+                             const float* mean, const float* invstd, const float* weight, const float* sums, double count,
+                             int32_t relu, int64_t rows, int32_t C, float* dx, float* dresidual, void* stream) {
   if (!dy || !x || !mean || !invstd || !sums || !dx) return bad("null pointer");
-  if (relu && !y) return bad("relu backward needs the forward output y");
+  if (relu && !y && !scale_shift) return bad("relu backward needs the forward output y or the forward's scale_shift");
+  if ((uintptr_t)scale_shift & 15) return bad("scale_shift must be 16-byte aligned");
   if (!(count >= 1.0)) return bad("count must be >= 1");
   if (int e = bn_shape_ok(rows, C)) return e;
   if (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)y | (uintptr_t)dx | (uintptr_t)dresidual | (uintptr_t)mean |
        (uintptr_t)invstd | (uintptr_t)weight | (uintptr_t)sums) & 15)
     return bad("batch norm backward operands must be 16-byte aligned");
-  return run_bn_bwd_apply(dy, x, y, mean, invstd, weight, sums, count, relu, rows, C, dx, dresidual, (hipStream_t)stream);
+  return run_bn_bwd_apply(dy, x, y, scale_shift, mean, invstd, weight, sums, count, relu, rows, C, dx, dresidual,
+                          (hipStream_t)stream);
 }
 
 }  // extern "C"

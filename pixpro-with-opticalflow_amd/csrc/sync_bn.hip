@@ -176,17 +176,30 @@ k_apply(const float* __restrict__ x, const float* __restrict__ res, const float*
 #undef BODY
 }
 
-// partial[by][0][C] = sum dz, partial[by][1][C] = sum dz * (x - mean);  dz = dy masked by y > 0 when RELU
-template <bool RELU>
+// ReLU decision of the forward pass for one float4: MODE 1 reads the saved output y, MODE 2 recomputes it from x with
+// the forward's own scale / shift and the same fma (no residual in that case), MODE 0: no ReLU.
+#define BN_MASK(MODE, g, v, i)                                                                                 \
+    if (MODE == 1) { const float4 o = ld4(y, i); g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f;      \
+                     g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f; }                               \
+    if (MODE == 2) { g.x = __builtin_fmaf(v.x, sc.x, sf.x) > 0.f ? g.x : 0.f;                                  \
+                     g.y = __builtin_fmaf(v.y, sc.y, sf.y) > 0.f ? g.y : 0.f;                                  \
+                     g.z = __builtin_fmaf(v.z, sc.z, sf.z) > 0.f ? g.z : 0.f;                                  \
+                     g.w = __builtin_fmaf(v.w, sc.w, sf.w) > 0.f ? g.w : 0.f; }
+
+// partial[by][0][C] = sum dz, partial[by][1][C] = sum dz * (x - mean);  dz = dy masked by the forward's ReLU decision
+template <int MODE>
 __global__ void __launch_bounds__(BN_TPB)
 k_bwd_reduce(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ y,
-             const float* __restrict__ mean, float* __restrict__ partial, int64_t M, int C4, int TX, int TY) {
+             const float* __restrict__ scale_shift, const float* __restrict__ mean, float* __restrict__ partial,
+             int64_t M, int C4, int TX, int TY) {
   __shared__ float4 sh[2 * BN_TPB];
   float4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
-  const float4 mu = ld4(mean, blockIdx.x * TX + (threadIdx.x & (TX - 1)));
+  const int cc = blockIdx.x * TX + (threadIdx.x & (TX - 1));
+  const float4 mu = ld4(mean, cc);
+  float4 sc = mu, sf = mu;
+  if (MODE == 2) { sc = ld4(scale_shift, cc); sf = ld4(scale_shift + (int64_t)C4 * 4, cc); }
 #define BODY(row) { const int64_t i = (row) * C4 + c4; float4 g = ld4(dy, i); const float4 v = ld4(x, i);       \
-    if (RELU) { const float4 o = ld4(y, i); g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f;           \
-                g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f; }                                    \
+    BN_MASK(MODE, g, v, i)                                                                                     \
     s.x += g.x; s.y += g.y; s.z += g.z; s.w += g.w;                                                            \
     q.x = __builtin_fmaf(g.x, v.x - mu.x, q.x); q.y = __builtin_fmaf(g.y, v.y - mu.y, q.y);                    \
     q.z = __builtin_fmaf(g.z, v.z - mu.z, q.z); q.w = __builtin_fmaf(g.w, v.w - mu.w, q.w); }
@@ -216,10 +229,11 @@ k_bwd_finalize(const float* __restrict__ partial, int nblk, int C, const float* 
 }
 
 // dx = (dz - sum_dz/n - (x - mean) * invstd^2 * sum_dz_xmu/n) * invstd * w        (batch_norm_backward_elemt)
-template <bool RELU, bool RES>
+template <int MODE, bool RES>
 __global__ void __launch_bounds__(BN_TPB)
 k_bwd_apply(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ y,
-            const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ weight,
+            const float* __restrict__ scale_shift, const float* __restrict__ mean, const float* __restrict__ invstd,
+            const float* __restrict__ weight,
             const float* __restrict__ sums, float inv_n, float* __restrict__ dx, float* __restrict__ dres, int64_t M,
             int C4, int TX, int TY) {
   const int cc = blockIdx.x * TX + (threadIdx.x & (TX - 1));
@@ -227,6 +241,8 @@ k_bwd_apply(const float* __restrict__ dy, const float* __restrict__ x, const flo
   const float4 mu = ld4(mean, cc), is = ld4(invstd, cc);
   const float4 w = weight ? ld4(weight, cc) : make_float4(1.f, 1.f, 1.f, 1.f);
   const float4 sd = ld4(sums, cc), sx = ld4(sums + C, cc);
+  float4 sc = mu, sf = mu;
+  if (MODE == 2) { sc = ld4(scale_shift, cc); sf = ld4(scale_shift + C, cc); }
   // dx = dz * a + (x - mean) * b + c  per channel
   float4 a, b, c;
   a.x = is.x * w.x; a.y = is.y * w.y; a.z = is.z * w.z; a.w = is.w * w.w;
@@ -234,8 +250,7 @@ k_bwd_apply(const float* __restrict__ dy, const float* __restrict__ x, const flo
   b.z = -(sx.z * inv_n) * is.z * is.z * a.z; b.w = -(sx.w * inv_n) * is.w * is.w * a.w;
   c.x = -(sd.x * inv_n) * a.x; c.y = -(sd.y * inv_n) * a.y; c.z = -(sd.z * inv_n) * a.z; c.w = -(sd.w * inv_n) * a.w;
 #define BODY(row) { const int64_t i = (row) * C4 + c4; float4 g = ld4(dy, i); const float4 v = ld4(x, i);       \
-    if (RELU) { const float4 o = ld4(y, i); g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f;           \
-                g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f; }                                    \
+    BN_MASK(MODE, g, v, i)                                                                                     \
     if (RES) st4(dres, i, g);                                                                                 \
     float4 o2;                                                                                                \
     o2.x = __builtin_fmaf(g.x, a.x, __builtin_fmaf(v.x - mu.x, b.x, c.x));                                    \
@@ -286,12 +301,21 @@ int run_bn_apply(const float* gathered, int W, const float* x, const float* res,
   return PIXPRO_OK;
 }
 
-int run_bn_bwd_reduce(const float* dy, const float* x, const float* y, const float* mean, const float* invstd, int relu,
-                      int64_t M, int C, float* ws, float* sums, float* grad_weight, float* grad_bias, hipStream_t st) {
+// ReLU decision source: 0 none, 1 the saved output y, 2 recomputed from x (scale_shift given)
+static inline int mask_mode(int relu, const float* scale_shift) { return !relu ? 0 : (scale_shift ? 2 : 1); }
+
+int run_bn_bwd_reduce(const float* dy, const float* x, const float* y, const float* scale_shift, const float* mean,
+                      const float* invstd, int relu, int64_t M, int C, float* ws, float* sums, float* grad_weight,
+                      float* grad_bias, hipStream_t st) {
   const BnTile t = bn_tile(M, C / 4);
   const dim3 g(t.gx, t.gy), b(BN_TPB);
-  if (relu) hipLaunchKernelGGL((k_bwd_reduce<true>), g, b, 0, st, dy, x, y, mean, ws, M, C / 4, t.TX, t.TY);
-  else hipLaunchKernelGGL((k_bwd_reduce<false>), g, b, 0, st, dy, x, y, mean, ws, M, C / 4, t.TX, t.TY);
+#define REDUCE(MD) hipLaunchKernelGGL((k_bwd_reduce<MD>), g, b, 0, st, dy, x, y, scale_shift, mean, ws, M, C / 4, t.TX, t.TY)
+  switch (mask_mode(relu, scale_shift)) {
+    case 0: REDUCE(0); break;
+    case 1: REDUCE(1); break;
+    default: REDUCE(2); break;
+  }
+#undef REDUCE
   CHECKED("k_bwd_reduce");
   hipLaunchKernelGGL(k_bwd_finalize, dim3((C + FIN_CH - 1) / FIN_CH), dim3(BN_TPB), 0, st, ws, t.gy, C, invstd, sums, grad_weight,
                      grad_bias);
@@ -299,18 +323,17 @@ int run_bn_bwd_reduce(const float* dy, const float* x, const float* y, const flo
   return PIXPRO_OK;
 }
 
-int run_bn_bwd_apply(const float* dy, const float* x, const float* y, const float* mean, const float* invstd,
-                     const float* weight, const float* sums, double count, int relu, int64_t M, int C, float* dx,
-                     float* dres, hipStream_t st) {
+int run_bn_bwd_apply(const float* dy, const float* x, const float* y, const float* scale_shift, const float* mean,
+                     const float* invstd, const float* weight, const float* sums, double count, int relu, int64_t M, int C,
+                     float* dx, float* dres, hipStream_t st) {
   const BnTile t = bn_tile(M, C / 4);
   const dim3 g(t.gx, t.gy), b(BN_TPB);
   const float inv_n = (float)(1.0 / count);
-#define BAPPLY(R, S) hipLaunchKernelGGL((k_bwd_apply<R, S>), g, b, 0, st, dy, x, y, mean, invstd, weight, sums, inv_n, \
-                                        dx, dres, M, C / 4, t.TX, t.TY)
-  if (relu && dres) BAPPLY(true, true);
-  else if (relu) BAPPLY(true, false);
-  else if (dres) BAPPLY(false, true);
-  else BAPPLY(false, false);
+#define BAPPLY(MD, S) hipLaunchKernelGGL((k_bwd_apply<MD, S>), g, b, 0, st, dy, x, y, scale_shift, mean, invstd, weight, \
+                                         sums, inv_n, dx, dres, M, C / 4, t.TX, t.TY)
+  const int mode = mask_mode(relu, scale_shift);
+  if (dres) { if (mode == 0) BAPPLY(0, true); else if (mode == 1) BAPPLY(1, true); else BAPPLY(2, true); }
+  else { if (mode == 0) BAPPLY(0, false); else if (mode == 1) BAPPLY(1, false); else BAPPLY(2, false); }
 #undef BAPPLY
   CHECKED("k_bwd_apply");
   return PIXPRO_OK;
