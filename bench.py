@@ -120,6 +120,47 @@ class KernelClock:
         return {k: sum(s.elapsed_time(e) for s, e in v) / len(v) for k, v in self.pairs.items()}
 
 
+class BnAudit:
+    """One extra, untimed step with a HIP-event pair around every batch-norm C-ABI call and the tensor passes each call
+    makes (rows * C * 4 B per pass): achieved HBM rate of the BN + ReLU + residual kernels."""
+
+    PASSES = {   # name -> (index of rows, index of C, function(args) -> tensor passes)
+        "pixpro_bn_stats": (1, 2, lambda a: 1),
+        "pixpro_bn_apply": (11, 12, lambda a: 2 + (a[3] is not None)),
+        "pixpro_bn_backward_reduce": (7, 8, lambda a: 2 + (a[6] != 0 and a[3] is None)),
+        "pixpro_bn_backward_apply": (10, 11, lambda a: 3 + (a[9] != 0 and a[3] is None) + (a[13] is not None)),
+    }
+
+    def __init__(self):
+        self.rec = []
+
+    def install(self, native):
+        self.native, self.inner = native, native.call
+
+        def call(name, *a):
+            spec = self.PASSES.get(name)
+            if spec is None:
+                return self.inner(name, *a)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            self.inner(name, *a)
+            e.record()
+            self.rec.append((name, s, e, a[spec[0]] * a[spec[1]] * 4 * spec[2](a)))
+        native.call = call
+
+    def remove(self):
+        self.native.call = self.inner
+
+    def summary(self):
+        out = {}
+        for name, s, e, nbytes in self.rec:
+            o = out.setdefault(name.replace("pixpro_", ""), [0, 0.0, 0])
+            o[0] += 1
+            o[1] += s.elapsed_time(e)
+            o[2] += nbytes
+        return out
+
+
 def cpu_baseline(a, args):
     """The oracle on the host cores: file-mode flow preparation for `cpu_flow_images` images at 720x1280 and
     PPM+loss forward+backward for one full batch; reported as hot-path images/s."""
@@ -286,6 +327,14 @@ def main():
         elapsed = t.item()
     final_loss = loss.item()
     ms = clock.mean_ms()
+    bn = None
+    if a.fused_bn and rank == 0 and world == 1:
+        audit = BnAudit()
+        audit.install(_native)
+        main_pretrain.train_step(model, optimizer, scheduler, next(iter(loader)), args)
+        torch.cuda.synchronize()
+        audit.remove()
+        bn = audit.summary()
     note(rank, f"timed {a.steps} steps in {elapsed:.2f} s; hot kernels (ms): {ms}")
 
     if rank == 0:
@@ -324,6 +373,18 @@ def main():
                 kernels[extra] = {"bound": "hbm", "achieved": round(nbytes / t / 1e9, 1), "peak": HBM_PEAK / 1e9,
                                   "unit": "GB/s", "frac": round(nbytes / t / HBM_PEAK, 4), "traffic": None,
                                   "ms_per_launch": round(ms[extra], 4), "algorithmic_bytes_per_launch": nbytes}
+        if bn:
+            n_l = sum(v[0] for v in bn.values())
+            t_ms = sum(v[1] for v in bn.values())
+            nb = sum(v[2] for v in bn.values())
+            kernels["batch_norm"] = {"bound": "hbm", "achieved": round(nb / (t_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK / 1e9,
+                                     "unit": "GB/s", "frac": round(nb / (t_ms * 1e-3) / HBM_PEAK, 4), "traffic": None,
+                                     "ms_per_step": round(t_ms, 3), "launch_pairs_per_step": n_l,
+                                     "algorithmic_bytes_per_step": int(nb),
+                                     "by_call": {k: {"n": v[0], "ms": round(v[1], 3),
+                                                     "GB/s": round(v[2] / (v[1] * 1e-3) / 1e9, 1)} for k, v in bn.items()},
+                                     "note": "fused (Sync)BatchNorm + ReLU + residual add, one audited step; bytes = tensor "
+                                             "passes x rows x C x 4 (DESIGN.md 4.7)"}
         cand = [k for k in ("flow_prepare", "ppm_loss") if k in kernels]
         dominant = max(cand, key=lambda k: kernels[k]["ms_per_launch"]) if cand else None
         out = {

@@ -211,3 +211,41 @@ def test_train_step_lazy_flow_matches_dense(dev):
     assert abs(out[0][0] - out[1][0]) <= 1e-5 * max(1.0, abs(out[0][0]))
     assert torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][2], out[1][2])
     assert out[0][1].sum() > 0
+
+
+def test_train_step_fused_bn_and_checkpoint_interchange(dev, tmp_path):
+    """main_pretrain with --fused-bn --channels-last: the step runs, the loss falls, and its checkpoint loads into a
+    model built WITHOUT the fused modules (same state-dict names), giving the same evaluation-mode features."""
+    import main_pretrain
+    from contrast import option
+    from contrast.lr_scheduler import get_scheduler
+    from contrast.synthetic import make_batch
+    from contrast.sync_bn import FusedSyncBatchNorm
+    base = ["--model", "PixPro", "--arch", "resnet18", "--synthetic", "--use_flow", "--use_flow_file", "--flow_up",
+            "--alpha1", "0.01", "--alpha2", "0.5", "--n-frames", "2", "--optimizer", "lars", "--base-lr", "1.0",
+            "--weight-decay", "1e-5", "--amp-opt-level", "O0", "--pixpro-p", "2", "--pixpro-transform-layer", "1",
+            "--batch-size", "8", "--epochs", "2", "--warmup-epoch", "0", "--head-type", "early_return",
+            "--output-dir", str(tmp_path)]
+    data = make_batch(8, image_size=64, n_frames=2, frame_hw=(96, 128), device=dev, sigma=0.8, channels_last=True)
+    args = option.parse_option(argv=base + ["--fused-bn", "--channels-last"])
+    args.num_instances = 32
+    torch.manual_seed(0)
+    model, opt = main_pretrain.build_model(args, dev)
+    assert sum(isinstance(m, FusedSyncBatchNorm) for m in model.modules()) == 2 * (20 + 1)
+    sched = get_scheduler(opt, 4, args)
+    model.train()
+    losses = [main_pretrain.train_step(model, opt, sched, data, args)[0].item() for _ in range(6)]
+    assert all(l == l for l in losses) and losses[-1] < losses[0]
+    main_pretrain.save_checkpoint(args, 1, model, opt, sched)
+
+    args2 = option.parse_option(argv=base)
+    args2.num_instances = 32
+    model2, opt2 = main_pretrain.build_model(args2, dev)
+    assert list(model2.state_dict().keys()) == list(model.state_dict().keys())
+    args2.resume = str(tmp_path / "current.pth")
+    main_pretrain.load_checkpoint(args2, model2, opt2, get_scheduler(opt2, 4, args2))
+    model.eval(), model2.eval()
+    im = data[0]
+    with torch.no_grad():
+        a, b = model.encoder(im), model2.encoder(im)
+    assert torch.allclose(a, b, rtol=1e-4, atol=1e-5)
