@@ -288,7 +288,10 @@ def main():
     args = model_args(a, world)
     # MIOpen immediate mode: this image ships no gfx950 find-db, and an exhaustive find on a fresh box
     # compiles for many minutes; the heuristic picks the prebuilt CK implicit-GEMM kernels at once
+    from contrast.miopen_tuning import use_shipped_db
+    tuned = use_shipped_db()      # MIOpen's own find-db for these shapes, recorded on an MI355X (contrast/miopen_tuning.py)
     torch.backends.cudnn.benchmark = bool(int(os.environ.get("PIXPRO_MIOPEN_FIND", "0")))
+    note(rank, f"MIOpen: shipped find-db {'in use' if tuned else 'not used'}, find mode {torch.backends.cudnn.benchmark}")
     torch.manual_seed(1234 + rank)
     loader = SyntheticLoader(a.steps + a.warmup, a.batch, pool=2, image_size=a.image_size, n_frames=a.n_frames,
                              frame_hw=(720, 1280), device=dev, seed=1234 + rank, channels_last=a.channels_last)
