@@ -169,6 +169,8 @@ def main_prog(opt):
         with open(os.path.join(opt.output_dir, "config.json"), "w") as f:
             json.dump({k: v for k, v in vars(opt).items()}, f, indent=2, default=str)
     device = torch.device("cuda", opt.local_rank)
+    from contrast.miopen_tuning import use_shipped_db
+    use_shipped_db()    # MIOpen's recorded find-db for the ResNet-50 shapes; other shapes are tuned by benchmark mode
     torch.backends.cudnn.benchmark = not opt.no_benchmark
     main(opt, device)
 
