@@ -324,6 +324,29 @@ __device__ __forceinline__ void gemm_pp(f32x4& acc0, f32x4& acc1, const float* _
   }
 }
 
+// Positive-pair test `sqrtf(d2) / diag < r` (PixPro.py:217-219) as `d2 < T`: correctly rounded sqrt and division are
+// monotone, so the set of d2 that pass is a down-set of the non-negative floats; T is its supremum, found by a 64-ary
+// search over the bit patterns (6 rounds of one sqrt + one division per lane, run by one wave while the tiles are in
+// flight).  The 49 x 49 tests then cost two multiplies, an add and a compare each - and decide exactly as the reference.
+__device__ __forceinline__ float dist_threshold(float diag, float r, int lane) {
+  if (!(r == r) || !(diag > 0.f)) return 0.f;          // NaN ratio, zero / NaN diagonal: nothing passes
+  long long lo = -1, hi = 0x7f800000LL + 1;            // test(lo) passes (or lo = -1); test(hi) fails (or hi = sentinel)
+  while (hi - lo > 1) {
+    const long long step = (hi - lo - 1 + 63) / 64;
+    const long long c = lo + (long long)(lane + 1) * step;
+    const bool in = c < hi;
+    bool fails = true;
+    if (in) fails = (sqrtf(__uint_as_float((unsigned)c)) / diag) >= r;
+    const unsigned long long m = __ballot(fails);
+    const int first = m ? __ffsll((long long)m) - 1 : 64;
+    const long long nlo = lo + (long long)first * step;
+    const long long c1 = lo + (long long)(first + 1) * step;
+    hi = first < 64 ? (c1 < hi ? c1 : hi) : hi;
+    lo = nlo;
+  }
+  return __uint_as_float(hi > 0x7f800000LL ? 0x7f800000u : (unsigned)hi);
+}
+
 // PC: compile-time P (49 for the 7x7 grid of 224^2 crops) so that every tile index folds into immediates;
 // 0 = run-time P.
 template <int MT, int NT, int PC>
@@ -426,9 +449,17 @@ ppm_fused_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* _
         qx = ox; qy = oy;
       }
       valid = v ? 1 : 0;
-      if (tid == 0) sm.misc[0] = fmaxf(bin_diag(cq, wo1, ho1), bin_diag(ck, wo1, ho1));
     }
     sm.qx[tid] = qx; sm.qy[tid] = qy; sm.kx[tid] = kx; sm.ky[tid] = ky; sm.valid[tid] = valid;
+  }
+  if (wave == 1) {                  // threshold of the positive-pair test (needs only the two crop records)
+    int Ho, Wo;
+    frame_size(pb, dd, Ho, Wo);
+    const float wo1 = (float)(Wo - 1), ho1 = (float)(Ho - 1);
+    const float diag = fmaxf(bin_diag(crop_of(dd.coord_q + (size_t)n * 10, pb.H, pb.W), wo1, ho1),
+                             bin_diag(crop_of(dd.coord_k + (size_t)n * 10, pb.H, pb.W), wo1, ho1));
+    const float T = dist_threshold(diag, pb.pos_ratio, lane);
+    if (lane == 0) sm.misc[2] = T;
   }
   PUT_TILE(pfa, sm.B0);
   PUT_TILE(pfb, sm.B1);
@@ -438,15 +469,14 @@ ppm_fused_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* _
 
   // ---- positive-pair bit mask: row i of M = ballot over j (PixPro.py:217-223) ----
   {
-    const float diag = sm.misc[0];
+    const float T = sm.misc[2];     // sqrtf(d2) / diag < pos_ratio  <=>  d2 < T  (dist_threshold)
     const float kxj = sm.kx[lane], kyj = sm.ky[lane];
     int cnt_w = 0;
     for (int i = wave; i < 64; i += NWAVES) {
       bool pred = false;
       if (i < P && lane < P) {
         const float dx = sm.qx[i] - kxj, dy = sm.qy[i] - kyj;
-        const float dist = sqrtf(dx * dx + dy * dy) / diag;
-        pred = (dist < pb.pos_ratio) && (sm.valid[i] != 0);
+        pred = (dx * dx + dy * dy < T) && (sm.valid[i] != 0);
       }
       const unsigned long long bits = __ballot(pred);
       if (lane == 0) sm.mbits[i] = bits;
