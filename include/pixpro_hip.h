@@ -177,6 +177,16 @@ int pixpro_lars_sgd_step(float* const* p_ptrs, const float* const* g_ptrs,
                          float trust_coef, float eps, int32_t first_step, float* norms2,
                          void* stream);
 
+/* ---- RAFT correlation lookup (reference contrast/flow/corr.py:29-50 CorrBlock.__call__) -------
+ * level_l: [B*h*w, h2>>l, w2>>l] correlation maps (level 0 = all-pairs volume, then 2x2 average pools); coords
+ * [B,2,h,w] = current match position (x, y) of every frame-1 pixel in level-0 pixels.
+ * out [B, num_levels*(2r+1)^2, h, w]; channel (l, i, j) = bilinear sample (zeros padding, align_corners) of the
+ * pixel's level-l map at (x/2^l + i - r, y/2^l + j - r).  One launch for all levels and taps. */
+int pixpro_corr_lookup(const float* level0, const float* level1, const float* level2,
+                       const float* level3, int32_t num_levels, const float* coords, float* out,
+                       int32_t B, int32_t h, int32_t w, int32_t h2, int32_t w2, int32_t radius,
+                       void* stream);
+
 /* ---- (Sync)BatchNorm with ReLU / residual add folded in ----------
  * Replaces what torch.nn.SyncBatchNorm (installed by contrast/models/PixPro.py:289-292) runs per layer in training mode
  * (torch/nn/modules/_functions.py: batch_norm_stats, batch_norm_gather_stats_with_counts, batch_norm_elemt,

@@ -60,6 +60,7 @@ SIGNATURES = {
     "pixpro_ema_update": (ctypes.c_int, [_vp, _vp, _vp, _i32, _f64, _vp]),
     "pixpro_lars_sgd_step": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _f32, _f32, _f32, _f32, _i32,
                                             _vp, _vp]),
+    "pixpro_corr_lookup": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "pixpro_bn_workspace_bytes": (_sz, [_i64, _i32]),
     "pixpro_bn_stats": (ctypes.c_int, [_vp, _i64, _i32, _vp, _sz, _vp, _vp]),
     "pixpro_bn_apply": (ctypes.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _i32, _i64, _i32,

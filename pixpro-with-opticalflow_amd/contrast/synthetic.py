@@ -45,7 +45,7 @@ def smooth_noise(shape, sigma, gen, device):
 
 
 def make_batch(n, image_size=224, n_frames=2, frame_hw=(720, 1280), seed=1234, device="cuda", sigma=0.5,
-               flow_up=True, with_flow=True, channels_last=False):
+               flow_up=True, with_flow=True, channels_last=False, with_frames=False):
     Ho, Wo = frame_hw
     gen = torch.Generator(device=device).manual_seed(seed)
     rng = random.Random(seed)
@@ -60,6 +60,16 @@ def make_batch(n, image_size=224, n_frames=2, frame_hw=(720, 1280), seed=1234, d
     target = torch.zeros(n, dtype=torch.long, device=device)
     size = torch.tensor([Ho, Wo], device=device).repeat(n, 1)
     num_img = torch.full((n, 1), n_frames, device=device)
+    if with_frames:
+        # online flow mode: the original frames (0..255, smooth, each a slightly shifted copy of the previous one) travel
+        # in data[6][2:] as load_img_for_raft yields them (reference contrast/data/dataset.py:337-340,493-497)
+        base = torch.nn.functional.interpolate(torch.rand(n, 3, Ho // 16 + 2, Wo // 16 + 2, generator=gen, device=device),
+                                               size=(Ho + n_frames, Wo + 2 * n_frames), mode="bilinear",
+                                               align_corners=True) * 255.0
+        # frame t: the scene moved by (+2, -1) pixels per frame
+        frames = [base[:, :, t:t + Ho, 2 * (n_frames - 1 - t):2 * (n_frames - 1 - t) + Wo].contiguous()
+                  for t in range(n_frames)]
+        return [im1, im2, coord1, coord2, index, target, [size, num_img] + frames]
     if not with_flow:
         return [im1, im2, coord1, coord2, index, target, [size, num_img]]
     h, w = (Ho // 8, Wo // 8) if flow_up else (Ho, Wo)

@@ -5,9 +5,11 @@ forward_backward_consistency :253, concat_flow :301, normalize_coord :334, norma
 denormalize_flow :352, calc_mask_ratio :361, AverageMeter :10, reduce_tensor :64); `upflow8` is the
 reference's contrast/flow/utils/utils.py:87.  `calc_frame_ratio` is called by the reference's
 main_pretrain.py:230 but defined nowhere (defect D1); it is defined here with the contract its caller
-needs.  The online-RAFT branch of apply_optical_flow is out of scope and raises.
+needs.  The online branch (a RAFT flow model instead of flow files, util.py:76-171,200-203) runs contrast/flow/raft.py
+per frame pair and then the same fused preparation as the file branch.
 """
 import argparse
+import os
 
 import torch
 import torch.distributed as dist
@@ -210,25 +212,76 @@ def calc_frame_ratio(cur_n_frames):
     return mean_n_frames, no_of_r, torch.tensor(rows)
 
 
+def load_flow_model(args, device="cuda"):
+    """The flow-model set-up of the reference's main_pretrain.py:44-58: RAFT from `args.flow_model` (`small` in the file
+    name selects RAFT-small, option.py:107-110), DataParallel `module.` prefixes stripped, eval mode, frozen."""
+    from .flow import RAFT
+    if args.flow_model is None or not os.path.isfile(args.flow_model):
+        raise FileNotFoundError(f"not exit flow model path {args.flow_model}")
+    if "small" in os.path.basename(args.flow_model):
+        args.small = True
+    args.mixed_precision = False
+    model = RAFT(args)
+    weights = torch.load(args.flow_model, map_location="cpu", weights_only=True)
+    model.load_state_dict({(k[7:] if k.startswith("module.") else k): v for k, v in weights.items()})
+    model = model.to(device).eval()
+    for p in model.parameters():
+        p.requires_grad = False
+    return model
+
+
+@torch.no_grad()
+def calc_optical_flow(imgs, flow_model, up=False, verbose=False):
+    """util.py:76-102: forward flows of consecutive frame pairs and backward flows of the time-reversed clip,
+    [F-1, N, 2, h', w'] each (1/8 resolution, or full resolution when `up`)."""
+    assert len(imgs) >= 2
+    i = 1 if up else 0
+    flow_model.eval()
+    fwd = torch.stack([flow_model(a, b, upsample=False, test_mode=True)[i] for a, b in zip(imgs[:-1], imgs[1:])])
+    bwd = torch.stack([flow_model(a, b, upsample=False, test_mode=True)[i] for a, b in zip(imgs[1:][::-1], imgs[:-1][::-1])])
+    return fwd, bwd
+
+
+def _online_flows(imgs, flow_model, args):
+    """Flows of every frame pair in loader layout [N,F-1,2,h',w'], computed `flow_bs` samples at a time (the all-pairs
+    volume of one 720x1280 pair is 1.1 GB; util.py:129-171).  RAFT-small up-samples with plain x8 bilinear interpolation
+    (update_block returns no mask), so with --flow_up its 1/8-resolution output is handed on and the fused preparation
+    up-samples lazily; the full model's convex up-sampling is materialised.  Returns (lo_f, lo_b, still_to_upsample)."""
+    lazy_up = bool(args.flow_up) and getattr(flow_model, "update_block").mask is None
+    want_up = bool(args.flow_up) and not lazy_up
+    bs = imgs[0].shape[0]
+    step = getattr(args, "flow_bs", None) or 8
+    fs, bs_ = [], []
+    for s in range(0, bs, step):
+        part = [im[s:s + step] for im in imgs]
+        f, b = calc_optical_flow(part, flow_model, up=want_up, verbose=getattr(args, "verbose", False))
+        fs.append(f.permute(1, 0, 2, 3, 4))
+        bs_.append(b.permute(1, 0, 2, 3, 4))
+    return torch.cat(fs).contiguous(), torch.cat(bs_).contiguous(), lazy_up
+
+
 @torch.no_grad()
 def apply_optical_flow(data, flow_model, args):
-    """File-mode branch of the reference's apply_optical_flow (util.py:174-248), fused:
-    permute + upflow8 + concat_flow (both directions) + the two consistency masks are ONE launch for
-    nframe=2 and three launches for nframe>2, and the up-sampled flows are never materialised.
-    data[5] = [target, flow_fwds[N,F-1,2,h,w], flow_bwds[N,F-1,2,h,w]]; data[6] = [size[N,2], num_img[N,1], ...].
+    """The reference's apply_optical_flow (util.py:174-248), fused: permute + upflow8 + concat_flow (both directions) +
+    the two consistency masks are ONE launch for nframe=2 and three launches for nframe>2, and the up-sampled flows are
+    never materialised.  File branch: data[5] = [target, flow_fwds[N,F-1,2,h,w], flow_bwds[N,F-1,2,h,w]]; online branch:
+    data[6] = [size[N,2], num_img[N,1], frame_0[N,3,H,W], ...] and `flow_model` = RAFT.
     Returns [flow_fwd[N,2,Hf,Wf], size, mask_fwd[N,Hf,Wf]], [flow_bwd, size, mask_bwd]."""
-    if not getattr(args, "use_flow_file", True):
-        raise NotImplementedError("online RAFT inference is out of scope; feed flows with --use_flow_file")
     if getattr(args, "use_flow_frames", False) and data[6][1][0].item() > 2:
         raise NotImplementedError("use_flow_frames is half-implemented in the reference (defect D5)")
-    if getattr(args, "flow_cat_norm", False):
-        return _apply_optical_flow_staged(data, args)
     size = data[6][0][0]
-    _, lo_f, lo_b = data[5]
+    up = bool(args.flow_up)
+    if getattr(args, "use_flow_file", True):
+        _, lo_f, lo_b = data[5]
+    else:
+        if flow_model is None:
+            raise RuntimeError("online flow mode needs a flow model (util.load_flow_model) or --use_flow_file")
+        lo_f, lo_b, up = _online_flows(list(data[6][2:]), flow_model, args)
+    if getattr(args, "flow_cat_norm", False):
+        return _apply_optical_flow_staged(lo_f, lo_b, size, up, args)
     lo_f = nv.dev_f32(lo_f, "flow_fwds")
     lo_b = nv.dev_f32(lo_b, "flow_bwds", lo_f.shape)
     N, F1, two, h, w = lo_f.shape
-    up = bool(args.flow_up)
     if getattr(args, "lazy_flow", False) and up and not getattr(args, "debug", False):
         # nothing is launched here: the loss kernel evaluates flow + mask at its sample points (ops.ppm_loss)
         fwd = LazyFlow(lo_f, lo_b, args.alpha1, args.alpha2)
@@ -256,14 +309,12 @@ def apply_optical_flow(data, flow_model, args):
     return [flow_fwd, size, mask_fwd], [flow_bwd, size, mask_bwd]
 
 
-def _apply_optical_flow_staged(data, args):
+def _apply_optical_flow_staged(lo_f, lo_b, size, up, args):
     """--flow_cat_norm variant (not used by the production recipes): the reference's stage order with
     one HIP launch per stage."""
-    size = data[6][0][0]
-    _, lo_f, lo_b = data[5]
     ff = lo_f.permute(1, 0, 2, 3, 4).contiguous()
     fb = lo_b.permute(1, 0, 2, 3, 4).contiguous()
-    if args.flow_up:
+    if up:
         num, nb, c, h, w = ff.shape
         ff = upflow8(ff.reshape(-1, c, h, w)).reshape(num, nb, c, 8 * h, 8 * w)
         fb = upflow8(fb.reshape(-1, c, h, w)).reshape(num, nb, c, 8 * h, 8 * w)

@@ -67,6 +67,8 @@ int run_lars(float* const* pp, const float* const* gp, float* const* bp, const i
              const int32_t* adapt, int count, float lr, float momentum, float trust, float eps, int first_step,
              float* norms2, hipStream_t st);
 int run_scale(float* buf, size_t n, const float* scale, hipStream_t st);
+int run_corr_lookup(const float* const* levels, int L, const float* coords, float* out, int B, int h, int w, int h2, int w2,
+                    int radius, hipStream_t st);
 size_t bn_workspace_floats(int64_t M, int C);
 int run_bn_stats(const float* x, int64_t M, int C, float* ws, float* packed, hipStream_t st);
 int run_bn_apply(const float* gathered, int W, const float* x, const float* res, const float* weight, const float* bias,
@@ -257,6 +259,19 @@ int pixpro_lars_sgd_step(float* const* p_ptrs, const float* const* g_ptrs, float
   if (count < 1 || count > 65535) return bad("count out of range");
   return run_lars(p_ptrs, g_ptrs, buf_ptrs, sizes, wd, adapt, count, lr, momentum, trust_coef, eps, first_step,
                   norms2, (hipStream_t)stream);
+}
+
+int pixpro_corr_lookup(const float* level0, const float* level1, const float* level2, const float* level3,
+                       int32_t num_levels, const float* coords, float* out, int32_t B, int32_t h, int32_t w, int32_t h2,
+                       int32_t w2, int32_t radius, void* stream) {
+  const float* levels[4] = {level0, level1, level2, level3};
+  if (num_levels < 1 || num_levels > 4) return bad("num_levels must be 1..4");
+  for (int l = 0; l < num_levels; ++l)
+    if (!levels[l]) return bad("null pyramid level");
+  if (!coords || !out) return bad("null pointer");
+  if (B < 1 || h < 1 || w < 1 || radius < 0 || radius > 16) return bad("B, h, w must be positive, radius in 0..16");
+  if ((h2 >> (num_levels - 1)) < 1 || (w2 >> (num_levels - 1)) < 1) return bad("pyramid level smaller than one pixel");
+  return run_corr_lookup(levels, num_levels, coords, out, B, h, w, h2, w2, radius, (hipStream_t)stream);
 }
 
 static int bn_shape_ok(int64_t rows, int32_t C) {

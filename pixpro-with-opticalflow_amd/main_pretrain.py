@@ -84,21 +84,39 @@ def load_pretrained(model, path):
     model.load_state_dict(sd)
 
 
-def prepare_step_inputs(data, args):
+def build_flow_model(args, device):
+    """main_pretrain.py:42-58: RAFT for the online flow mode (`--use_flow` without `--use_flow_file`).  With
+    --synthetic and no checkpoint a randomly initialised RAFT-small stands in (there are no weights offline)."""
+    if not args.use_flow or args.use_flow_file:
+        return None
+    if args.flow_model:
+        return util.load_flow_model(args, device)
+    if not args.synthetic:
+        raise FileNotFoundError(f"not exit flow model path {args.flow_model}")
+    from contrast.flow import RAFT
+    args.small, args.mixed_precision = True, False
+    log("no --flow_model given: randomly initialised RAFT-small (synthetic run)")
+    model = RAFT(args).to(device).eval()
+    for p in model.parameters():
+        p.requires_grad = False
+    return model
+
+
+def prepare_step_inputs(data, args, flow_model=None):
     """main_pretrain.py:224-251: flow preparation and the coord/flow packing the model expects."""
     coord1, coord2 = data[2], data[3]
     info = {}
     if args.use_flow:
-        flow_fwd, flow_bwd = util.apply_optical_flow(data, None, args)
+        flow_fwd, flow_bwd = util.apply_optical_flow(data, flow_model, args)
         info["mask_fwd"], info["mask_bwd"] = flow_fwd[2], flow_bwd[2]
         info["n_frames"] = data[6][1]
         coord1, coord2 = [coord1, flow_fwd], [coord2, flow_bwd]
     return coord1, coord2, info
 
 
-def train_step(model, optimizer, scheduler, data, args):
+def train_step(model, optimizer, scheduler, data, args, flow_model=None):
     """One pre-training step (main_pretrain.py:213-269) with no host synchronisation."""
-    coord1, coord2, info = prepare_step_inputs(data, args)
+    coord1, coord2, info = prepare_step_inputs(data, args, flow_model)
     loss, pos_num_list = model(data[0], data[1], coord1, coord2)
     optimizer.zero_grad()
     loss.backward()
@@ -107,13 +125,13 @@ def train_step(model, optimizer, scheduler, data, args):
     return loss, pos_num_list, info
 
 
-def train(epoch, loader, model, optimizer, scheduler, args):
+def train(epoch, loader, model, optimizer, scheduler, args, flow_model=None):
     model.train()
     loss_meter, time_meter = util.AverageMeter(), util.AverageMeter()
     is_mask_flow = args.use_flow and args.alpha1 is not None and args.alpha2 is not None
     end = time.time()
     for idx, data in enumerate(loader):
-        loss, pos_num_list, info = train_step(model, optimizer, scheduler, data, args)
+        loss, pos_num_list, info = train_step(model, optimizer, scheduler, data, args, flow_model)
         if idx % args.print_freq == 0:
             # all .item() syncs of the reference's per-step logging (main_pretrain.py:272-285) live here
             (pn1, pm1), (pn2, pm2) = pos_num_list
@@ -143,8 +161,9 @@ def main(args, device):
     size = args.image_size if isinstance(args.image_size, int) else args.image_size[0]
     loader = SyntheticLoader(args.steps_per_epoch, args.batch_size, image_size=size, n_frames=max(args.n_frames, 2),
                              frame_hw=tuple(args.frame_size), device=device, flow_up=args.flow_up,
-                             with_flow=args.use_flow, channels_last=getattr(args, "channels_last", False), seed=1234 + (dist.get_rank() if dist.is_initialized() else 0))
+                             with_flow=args.use_flow, with_frames=args.use_flow and not args.use_flow_file, channels_last=getattr(args, "channels_last", False), seed=1234 + (dist.get_rank() if dist.is_initialized() else 0))
     model, optimizer = build_model(args, device)
+    flow_model = build_flow_model(args, device)
     scheduler = get_scheduler(optimizer, len(loader), args)
     if args.pretrained_model:
         load_pretrained(model, args.pretrained_model)
@@ -155,7 +174,7 @@ def main(args, device):
     if args.resume:
         load_checkpoint(args, model, optimizer, scheduler)
     for epoch in range(args.start_epoch, args.epochs + 1):
-        train(epoch, loader, model, optimizer, scheduler, args)
+        train(epoch, loader, model, optimizer, scheduler, args, flow_model)
         rank0 = not dist.is_initialized() or dist.get_rank() == 0
         if rank0 and (epoch % args.save_freq == 0 or epoch == args.epochs):
             save_checkpoint(args, epoch, model, optimizer, scheduler)

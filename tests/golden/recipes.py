@@ -68,3 +68,23 @@ def seeded_state_dict(shapes, seed):
         else:
             out[name] = 0.1 * torch.randn(shape, generator=gen)
     return out
+
+
+def raft_state_dict(shapes, seed):
+    """Seeded RAFT weights: `seeded_state_dict` with the last flow-head convolution scaled down so that twelve
+    refinement iterations of a random network stay in a well-conditioned range (|flow| of a few 1/8-res pixels)."""
+    sd = seeded_state_dict(shapes, seed)
+    for k in sd:
+        if "flow_head.conv2" in k:
+            sd[k] = sd[k] * 0.05
+    return sd
+
+
+def raft_images(n, h, w, seed):
+    """A smooth random frame pair in 0..255 (second frame = first shifted by a few pixels + noise)."""
+    g = torch.Generator().manual_seed(seed)
+    base = torch.nn.functional.interpolate(torch.rand(n, 3, h // 8 + 2, w // 8 + 2, generator=g), size=(h + 8, w + 8),
+                                           mode="bilinear", align_corners=True) * 255.0
+    im1 = base[:, :, 4:4 + h, 4:4 + w].contiguous()
+    im2 = (base[:, :, 2:2 + h, 6:6 + w] + 2.0 * torch.randn(n, 3, h, w, generator=g)).clamp(0, 255).contiguous()
+    return im1, im2

@@ -18,7 +18,7 @@ NAMES = ["start", "load x,v + pts", "maskbits", "rv norms", "S gemm+epi", "Y gem
 def main():
     out = "/tmp/libpixpro_hip_stamps.so"
     srcs = [os.path.join(PKG, "csrc", f) for f in ("capi.hip", "ppm_fused.hip", "ppm_generic.hip", "flow_prep.hip",
-                                                   "multi_tensor.hip", "sync_bn.hip")]
+                                                   "multi_tensor.hip", "sync_bn.hip", "raft_corr.hip")]
     objs = []
     base = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off",
             "-DPIXPRO_STAMPS", "-fgpu-rdc"]
