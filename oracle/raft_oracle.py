@@ -28,7 +28,7 @@ def corr_lookup(pyramid, coords, radius):
     out = []
     for i, corr in enumerate(pyramid):
         d = torch.linspace(-r, r, 2 * r + 1)
-        delta = torch.stack(torch.meshgrid(d, d, indexing="ij"), dim=-1)                 # :37-39: (dy, dx) stacked
+        delta = torch.stack(torch.meshgrid(d, d, indexing="ij"), dim=-1).to(coords.device)   # :37-39: (dy, dx) stacked
         lvl = coords.reshape(B * h1 * w1, 1, 1, 2) / 2 ** i + delta.view(1, 2 * r + 1, 2 * r + 1, 2)   # :41-43
         H, W = corr.shape[-2:]
         xg, yg = lvl.split([1, 1], dim=-1)

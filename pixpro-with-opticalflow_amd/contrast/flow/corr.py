@@ -20,7 +20,11 @@ def build_pyramid(fmap1, fmap2, num_levels=4):
     B, D, H, W = fmap1.shape
     f1 = fmap1.reshape(B, D, H * W)
     f2 = fmap2.reshape(B, D, H * W)
-    corr = torch.matmul(f1.transpose(1, 2), f2) / torch.sqrt(torch.tensor(D).float())
+    # the 1/sqrt(dim) of corr.py:60 rides on the GEMM's alpha (one pass over the 829 MB/image volume less); it scales the
+    # fp32 accumulator, so the result differs from matmul-then-divide by at most the rounding of x*(1/s) against x/s
+    alpha = 1.0 / float(torch.sqrt(torch.tensor(D).float()))
+    corr = torch.baddbmm(torch.empty((1, 1, 1), dtype=f1.dtype, device=f1.device).expand(B, H * W, H * W),
+                         f1.transpose(1, 2), f2, beta=0.0, alpha=alpha)
     level = corr.reshape(B * H * W, 1, H, W)
     pyramid = [level]
     for _ in range(num_levels - 1):

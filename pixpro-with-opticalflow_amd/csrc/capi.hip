@@ -269,7 +269,7 @@ int pixpro_corr_lookup(const float* level0, const float* level1, const float* le
   for (int l = 0; l < num_levels; ++l)
     if (!levels[l]) return bad("null pyramid level");
   if (!coords || !out) return bad("null pointer");
-  if (B < 1 || h < 1 || w < 1 || radius < 0 || radius > 16) return bad("B, h, w must be positive, radius in 0..16");
+  if (B < 1 || h < 1 || w < 1 || radius < 0 || radius > 8) return bad("B, h, w must be positive, radius in 0..8");
   if ((h2 >> (num_levels - 1)) < 1 || (w2 >> (num_levels - 1)) < 1) return bad("pyramid level smaller than one pixel");
   return run_corr_lookup(levels, num_levels, coords, out, B, h, w, h2, w2, radius, (hipStream_t)stream);
 }
