@@ -31,6 +31,22 @@ class AverageMeter(object):
         self.avg = self.sum / self.count
 
 
+def accuracy(output, target, topk=(1,)):
+    """Top-k precision in percent for each k (reference util.py:33-47; used by the evaluation stages)."""
+    with torch.no_grad():
+        ranks = output.topk(max(topk), dim=1).indices
+        hit = ranks.eq(target.view(-1, 1))
+        return [hit[:, :k].any(dim=1).float().sum().mul_(100.0 / target.size(0)).reshape(1) for k in topk]
+
+
+def dist_collect(x):
+    """All-gather along dim 0 (reference util.py:50-61)."""
+    x = x.contiguous()
+    parts = [torch.empty_like(x) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, x)
+    return torch.cat(parts, dim=0)
+
+
 def reduce_tensor(tensor):
     rt = tensor.clone()
     dist.all_reduce(rt, op=dist.ReduceOp.SUM)
@@ -258,6 +274,24 @@ def _online_flows(imgs, flow_model, args):
         fs.append(f.permute(1, 0, 2, 3, 4))
         bs_.append(b.permute(1, 0, 2, 3, 4))
     return torch.cat(fs).contiguous(), torch.cat(bs_).contiguous(), lazy_up
+
+
+@torch.no_grad()
+def mem_reduce_calc_optical_flow(orig_imgs, flow_model, args):
+    """util.py:129-171 (use_flow_frames=False): RAFT over every frame pair `flow_bs` samples at a time, then the flow
+    chain; returns the composed flows as [1, N, 2, Hf, Wf] each, like the reference."""
+    if getattr(args, "use_flow_frames", False) and len(orig_imgs) > 2:
+        raise NotImplementedError("use_flow_frames is half-implemented in the reference (defect D5)")
+    lo_f, lo_b, up = _online_flows(list(orig_imgs), flow_model, args)
+    N, F1, _, h, w = lo_f.shape
+    Hf, Wf = (8 * h, 8 * w) if up else (h, w)
+    flow_fwd = torch.empty((N, 2, Hf, Wf), dtype=torch.float32, device=lo_f.device)
+    flow_bwd = torch.empty_like(flow_fwd)
+    nv.call("pixpro_flow_prepare", nv.ptr(lo_f), nv.ptr(lo_b), nv.ptr(flow_fwd), nv.ptr(flow_bwd), None, None, None,
+            N, F1, h, w, int(up), 0.0, 0.0, nv.stream())
+    if getattr(args, "flow_cat_norm", False):
+        flow_fwd, flow_bwd = normalize_flow(flow_fwd), normalize_flow(flow_bwd)
+    return flow_fwd.unsqueeze(0), flow_bwd.unsqueeze(0)
 
 
 @torch.no_grad()

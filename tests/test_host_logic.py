@@ -159,3 +159,10 @@ def test_fused_bn_conversion_keeps_names_and_has_no_cpu_route():
     bn = nn.BatchNorm2d(4)
     x, r = torch.randn(2, 4, 3, 3), torch.randn(2, 4, 3, 3)
     assert torch.equal(bn_act(bn, x, relu=True, residual=r), torch.relu(bn(x) + r))
+
+
+def test_accuracy_helper():
+    from contrast import util
+    out = torch.tensor([[0.1, 0.7, 0.2], [0.8, 0.1, 0.1], [0.2, 0.3, 0.5]])
+    top1, top2 = util.accuracy(out, torch.tensor([1, 0, 1]), topk=(1, 2))
+    assert abs(top1.item() - 200.0 / 3) < 1e-4 and top2.item() == 100.0

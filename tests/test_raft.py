@@ -128,6 +128,9 @@ def test_online_flow_mode_equals_file_mode_on_the_same_flows(dev):
     args.use_flow_file = True
     data2 = [None] * 5 + [[None, lo_f, lo_b], [size, torch.full((N, 1), F)]]
     (gf, _, gmf), (gb, _, gmb) = util.apply_optical_flow(data2, None, args)
+    mf_, mb_ = util.mem_reduce_calc_optical_flow(frames, model, args)       # public helper of the reference API
+    assert mf_.shape == (1, N, 2, H, W) and torch.allclose(mf_[0], ff, rtol=1e-4, atol=1e-3)
+    assert torch.allclose(mb_[0], fb, rtol=1e-4, atol=1e-3)
     # two evaluations of the same network are equal up to MIOpen's run-to-run re-association (~1e-5 relative)
     assert torch.allclose(ff, gf, rtol=1e-4, atol=1e-3) and torch.allclose(fb, gb, rtol=1e-4, atol=1e-3)
     assert (mf != gmf).float().mean().item() < 1e-3
