@@ -28,14 +28,17 @@ struct BnTile {
   int gx, gy;        // grid: channel chunks x row blocks
 };
 
-// C4 = C/4.  TX = largest power of two <= 64 dividing C4; row blocks sized for ~4 blocks of 256 threads per CU.
-inline BnTile bn_tile(int64_t M, int C4) {
+// C4 = C/4.  TX = largest power of two <= 64 dividing C4; `cap` = work-groups per launch.  Measured on MI355X over the
+// ResNet-50 layers (N=256): the read-only statistics kernel streams best with ~1 group per CU, the read+write kernels with
+// ~2, the three-tensor backward reduction with ~4 (more groups than that lose DRAM page locality, fewer lose latency hiding).
+constexpr int CAP_STATS = 256, CAP_APPLY = 512, CAP_BWD_REDUCE = 1024, CAP_BWD_APPLY = 512, CAP_MAX = 1024;
+inline BnTile bn_tile(int64_t M, int C4, int cap) {
   BnTile t;
   t.TX = 1;
   while (t.TX < 64 && C4 % (t.TX * 2) == 0) t.TX *= 2;
   t.TY = BN_TPB / t.TX;
   t.gx = C4 / t.TX;
-  int64_t want = std::max<int64_t>(1, 1024 / t.gx);
+  int64_t want = std::max<int64_t>(1, cap / t.gx);
   int64_t most = std::max<int64_t>(1, (M + (int64_t)t.TY * 4 - 1) / ((int64_t)t.TY * 4));   // >= 4 rows per thread
   t.gy = (int)std::min<int64_t>(std::min(want, most), 65535);
   return t;
@@ -270,12 +273,12 @@ k_bwd_apply(const float* __restrict__ dy, const float* __restrict__ x, const flo
 }  // namespace
 
 size_t bn_workspace_floats(int64_t M, int C) {
-  const BnTile t = bn_tile(M, C / 4);
+  const BnTile t = bn_tile(M, C / 4, CAP_MAX);
   return (size_t)t.gy * 2 * C;
 }
 
 int run_bn_stats(const float* x, int64_t M, int C, float* ws, float* packed, hipStream_t st) {
-  const BnTile t = bn_tile(M, C / 4);
+  const BnTile t = bn_tile(M, C / 4, CAP_STATS);
   hipLaunchKernelGGL(k_stats, dim3(t.gx, t.gy), dim3(BN_TPB), 0, st, x, ws, M, C / 4, t.TX, t.TY);
   CHECKED("k_stats");
   hipLaunchKernelGGL(k_stats_finalize, dim3((C + FIN_CH - 1) / FIN_CH), dim3(BN_TPB), 0, st, x, ws, t.gy, M, C, packed);
@@ -289,7 +292,7 @@ int run_bn_apply(const float* gathered, int W, const float* x, const float* res,
   hipLaunchKernelGGL(k_merge, dim3((C + 255) / 256), dim3(256), 0, st, gathered, W, C, weight, bias, running_mean,
                      running_var, momentum, eps, mean, invstd, scale_shift);
   CHECKED("k_merge");
-  const BnTile t = bn_tile(M, C / 4);
+  const BnTile t = bn_tile(M, C / 4, CAP_APPLY);
   const dim3 g(t.gx, t.gy), b(BN_TPB);
 #define APPLY(R, S) hipLaunchKernelGGL((k_apply<R, S>), g, b, 0, st, x, res, scale_shift, y, M, C / 4, t.TX, t.TY)
   if (relu && res) APPLY(true, true);
@@ -307,7 +310,7 @@ static inline int mask_mode(int relu, const float* scale_shift) { return !relu ?
 int run_bn_bwd_reduce(const float* dy, const float* x, const float* y, const float* scale_shift, const float* mean,
                       const float* invstd, int relu, int64_t M, int C, float* ws, float* sums, float* grad_weight,
                       float* grad_bias, hipStream_t st) {
-  const BnTile t = bn_tile(M, C / 4);
+  const BnTile t = bn_tile(M, C / 4, CAP_BWD_REDUCE);
   const dim3 g(t.gx, t.gy), b(BN_TPB);
 #define REDUCE(MD) hipLaunchKernelGGL((k_bwd_reduce<MD>), g, b, 0, st, dy, x, y, scale_shift, mean, ws, M, C / 4, t.TX, t.TY)
   switch (mask_mode(relu, scale_shift)) {
@@ -326,7 +329,7 @@ int run_bn_bwd_reduce(const float* dy, const float* x, const float* y, const flo
 int run_bn_bwd_apply(const float* dy, const float* x, const float* y, const float* scale_shift, const float* mean,
                      const float* invstd, const float* weight, const float* sums, double count, int relu, int64_t M, int C,
                      float* dx, float* dres, hipStream_t st) {
-  const BnTile t = bn_tile(M, C / 4);
+  const BnTile t = bn_tile(M, C / 4, CAP_BWD_APPLY);
   const dim3 g(t.gx, t.gy), b(BN_TPB);
   const float inv_n = (float)(1.0 / count);
 #define BAPPLY(MD, S) hipLaunchKernelGGL((k_bwd_apply<MD, S>), g, b, 0, st, dy, x, y, scale_shift, mean, invstd, weight, \
