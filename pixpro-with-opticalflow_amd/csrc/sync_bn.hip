@@ -15,6 +15,8 @@
 // Statistics are accumulated as shifted sums (pivot = the channel's first element), so the variance does not suffer
 // the E[x^2]-E[x]^2 cancellation; partial sums are combined in a fixed order (deterministic, no atomics).
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -31,7 +33,23 @@ struct BnTile {
 // C4 = C/4.  TX = largest power of two <= 64 dividing C4; `cap` = work-groups per launch.  Measured on MI355X over the
 // ResNet-50 layers (N=256): the read-only statistics kernel streams best with ~1 group per CU, the read+write kernels with
 // ~2, the three-tensor backward reduction with ~4 (more groups than that lose DRAM page locality, fewer lose latency hiding).
-constexpr int CAP_STATS = 256, CAP_APPLY = 512, CAP_BWD_REDUCE = 1024, CAP_BWD_APPLY = 512, CAP_MAX = 1024;
+constexpr int CAP_MAX = 1024;
+struct BnCaps { int stats, apply, bwd_reduce, bwd_apply; };
+// PIXPRO_BN_CAPS="stats,apply,bwd_reduce,bwd_apply" overrides the defaults (tuning knob, tools/bn_sweep.py)
+inline BnCaps bn_caps() {
+  static const BnCaps caps = [] {
+    BnCaps c{256, 512, 1024, 512};
+    if (const char* e = getenv("PIXPRO_BN_CAPS")) {
+      int a, b, d, f;
+      if (sscanf(e, "%d,%d,%d,%d", &a, &b, &d, &f) == 4) {
+        auto cl = [](int v) { return std::min(std::max(v, 1), CAP_MAX); };
+        c = BnCaps{cl(a), cl(b), cl(d), cl(f)};
+      }
+    }
+    return c;
+  }();
+  return caps;
+}
 inline BnTile bn_tile(int64_t M, int C4, int cap) {
   BnTile t;
   t.TX = 1;
@@ -278,7 +296,7 @@ size_t bn_workspace_floats(int64_t M, int C) {
 }
 
 int run_bn_stats(const float* x, int64_t M, int C, float* ws, float* packed, hipStream_t st) {
-  const BnTile t = bn_tile(M, C / 4, CAP_STATS);
+  const BnTile t = bn_tile(M, C / 4, bn_caps().stats);
   hipLaunchKernelGGL(k_stats, dim3(t.gx, t.gy), dim3(BN_TPB), 0, st, x, ws, M, C / 4, t.TX, t.TY);
   CHECKED("k_stats");
   hipLaunchKernelGGL(k_stats_finalize, dim3((C + FIN_CH - 1) / FIN_CH), dim3(BN_TPB), 0, st, x, ws, t.gy, M, C, packed);
@@ -292,7 +310,7 @@ int run_bn_apply(const float* gathered, int W, const float* x, const float* res,
   hipLaunchKernelGGL(k_merge, dim3((C + 255) / 256), dim3(256), 0, st, gathered, W, C, weight, bias, running_mean,
                      running_var, momentum, eps, mean, invstd, scale_shift);
   CHECKED("k_merge");
-  const BnTile t = bn_tile(M, C / 4, CAP_APPLY);
+  const BnTile t = bn_tile(M, C / 4, bn_caps().apply);
   const dim3 g(t.gx, t.gy), b(BN_TPB);
 #define APPLY(R, S) hipLaunchKernelGGL((k_apply<R, S>), g, b, 0, st, x, res, scale_shift, y, M, C / 4, t.TX, t.TY)
   if (relu && res) APPLY(true, true);
@@ -310,7 +328,7 @@ static inline int mask_mode(int relu, const float* scale_shift) { return !relu ?
 int run_bn_bwd_reduce(const float* dy, const float* x, const float* y, const float* scale_shift, const float* mean,
                       const float* invstd, int relu, int64_t M, int C, float* ws, float* sums, float* grad_weight,
                       float* grad_bias, hipStream_t st) {
-  const BnTile t = bn_tile(M, C / 4, CAP_BWD_REDUCE);
+  const BnTile t = bn_tile(M, C / 4, bn_caps().bwd_reduce);
   const dim3 g(t.gx, t.gy), b(BN_TPB);
 #define REDUCE(MD) hipLaunchKernelGGL((k_bwd_reduce<MD>), g, b, 0, st, dy, x, y, scale_shift, mean, ws, M, C / 4, t.TX, t.TY)
   switch (mask_mode(relu, scale_shift)) {
@@ -329,7 +347,7 @@ int run_bn_bwd_reduce(const float* dy, const float* x, const float* y, const flo
 int run_bn_bwd_apply(const float* dy, const float* x, const float* y, const float* scale_shift, const float* mean,
                      const float* invstd, const float* weight, const float* sums, double count, int relu, int64_t M, int C,
                      float* dx, float* dres, hipStream_t st) {
-  const BnTile t = bn_tile(M, C / 4, CAP_BWD_APPLY);
+  const BnTile t = bn_tile(M, C / 4, bn_caps().bwd_apply);
   const dim3 g(t.gx, t.gy), b(BN_TPB);
   const float inv_n = (float)(1.0 / count);
 #define BAPPLY(MD, S) hipLaunchKernelGGL((k_bwd_apply<MD, S>), g, b, 0, st, dy, x, y, scale_shift, mean, invstd, weight, \
