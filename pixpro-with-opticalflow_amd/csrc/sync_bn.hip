@@ -7,7 +7,7 @@
 // (profiles/r01_syncbn_microbench.txt).  These kernels keep the same split (local statistics | exchange | apply),
 // so the collectives stay where torch has them, and stream x as [M = N*H*W rows][C] with 16 B per lane:
 //
-//   forward   k_stats (1 read of x)  -> k_stats_finalize -> [all_gather of 2C+1 floats] -> k_merge -> k_apply
+//   forward   k_stats (1 read of x)  -> k_stats_finalize -> [all_gather of 2C+1 floats] -> k_apply (merges in its prologue)
 //             k_apply: y = relu?( (x-mean)*invstd*w + b (+ residual) )                      (read x [,res], write y)
 //   backward  k_bwd_reduce: dz = dy * (y > 0)?; sum dz, sum dz*(x-mean)                      (read dy, x [,y])
 //             -> k_bwd_finalize -> [all_reduce of 2C floats] -> k_bwd_apply: dx [, dres = dz] (read dy, x [,y])
@@ -148,14 +148,13 @@ k_stats_finalize(const float* __restrict__ x, const float* __restrict__ partial,
   if (c == 0) packed[2 * C] = (float)M;
 }
 
-// gathered [W][2C+1] -> mean, invstd (saved for backward), scale/shift for k_apply, running statistics
-// (batch_norm_gather_stats_with_counts: count-weighted merge; running_var takes the unbiased variance)
-__global__ void k_merge(const float* __restrict__ gathered, int W, int C, const float* __restrict__ weight,
-                        const float* __restrict__ bias, float* __restrict__ running_mean, float* __restrict__ running_var,
-                        float momentum, float eps, float* __restrict__ mean_out, float* __restrict__ invstd_out,
-                        float* __restrict__ scale_shift) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// Count-weighted merge of the ranks' statistics for one channel (batch_norm_gather_stats_with_counts), in double.
+struct BnMerged {
+  float mean, invstd, scale, shift, var_unbiased;
+};
+__device__ __forceinline__ BnMerged merge_channel(const float* __restrict__ gathered, int W, int C, int c,
+                                                  const float* __restrict__ weight, const float* __restrict__ bias,
+                                                  float eps) {
   const int64_t S = 2 * (int64_t)C + 1;
   double n = 0.0, md = 0.0;
   for (int r = 0; r < W; ++r) {
@@ -169,24 +168,43 @@ __global__ void k_merge(const float* __restrict__ gathered, int W, int C, const 
     const double nr = (double)gathered[r * S + 2 * C], d = (double)gathered[r * S + c] - md;
     v += nr * ((double)gathered[r * S + C + c] + d * d);
   }
-  const float m = (float)md;
-  const float var = (float)(v / n);
-  const float invstd = 1.f / sqrtf(var + eps);
-  mean_out[c] = m;
-  invstd_out[c] = invstd;
-  const float sc = (weight ? weight[c] : 1.f) * invstd;
-  scale_shift[c] = sc;
-  scale_shift[C + c] = (bias ? bias[c] : 0.f) - m * sc;
-  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
-  if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(v / fmax(n - 1.0, 1.0));
+  BnMerged o;
+  o.mean = (float)md;
+  o.invstd = 1.f / sqrtf((float)(v / n) + eps);
+  o.scale = (weight ? weight[c] : 1.f) * o.invstd;
+  o.shift = (bias ? bias[c] : 0.f) - o.mean * o.scale;
+  o.var_unbiased = (float)(v / fmax(n - 1.0, 1.0));
+  return o;
 }
 
+// gathered [W][2C+1] -> y = relu?(x * scale + shift (+ residual)).  Every work-group merges the statistics of its own
+// channels in its prologue (a few dozen flops per lane: cheaper than a separate launch per layer); the first row block
+// also publishes mean, invstd (saved for backward), scale/shift, and updates the running statistics (unbiased variance).
 template <bool RELU, bool RES>
 __global__ void __launch_bounds__(BN_TPB)
-k_apply(const float* __restrict__ x, const float* __restrict__ res, const float* __restrict__ scale_shift,
-        float* __restrict__ y, int64_t M, int C4, int TX, int TY) {
+k_apply(const float* __restrict__ gathered, int W, const float* __restrict__ weight, const float* __restrict__ bias,
+        float* __restrict__ running_mean, float* __restrict__ running_var, float momentum, float eps,
+        float* __restrict__ mean_out, float* __restrict__ invstd_out, float* __restrict__ scale_shift,
+        const float* __restrict__ x, const float* __restrict__ res, float* __restrict__ y, int64_t M, int C4, int TX, int TY) {
   const int cc = blockIdx.x * TX + (threadIdx.x & (TX - 1));
-  const float4 sc = ld4(scale_shift, cc), sf = ld4(scale_shift + (int64_t)C4 * 4, cc);
+  const int C = C4 * 4;
+  const bool publish = blockIdx.y == 0 && threadIdx.x / TX == 0;
+  float scv[4], sfv[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = 4 * cc + k;
+    const BnMerged mg = merge_channel(gathered, W, C, c, weight, bias, eps);
+    scv[k] = mg.scale; sfv[k] = mg.shift;
+    if (publish) {
+      mean_out[c] = mg.mean;
+      invstd_out[c] = mg.invstd;
+      scale_shift[c] = mg.scale;
+      scale_shift[C + c] = mg.shift;
+      if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mg.mean;
+      if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * mg.var_unbiased;
+    }
+  }
+  const float4 sc = make_float4(scv[0], scv[1], scv[2], scv[3]), sf = make_float4(sfv[0], sfv[1], sfv[2], sfv[3]);
 #define BODY(row) { const int64_t i = (row) * C4 + c4; const float4 v = ld4(x, i); float4 o;                   \
     o.x = __builtin_fmaf(v.x, sc.x, sf.x); o.y = __builtin_fmaf(v.y, sc.y, sf.y);                              \
     o.z = __builtin_fmaf(v.z, sc.z, sf.z); o.w = __builtin_fmaf(v.w, sc.w, sf.w);                              \
@@ -307,12 +325,10 @@ int run_bn_stats(const float* x, int64_t M, int C, float* ws, float* packed, hip
 int run_bn_apply(const float* gathered, int W, const float* x, const float* res, const float* weight, const float* bias,
                  float* running_mean, float* running_var, float momentum, float eps, int relu, int64_t M, int C,
                  float* y, float* mean, float* invstd, float* scale_shift, hipStream_t st) {
-  hipLaunchKernelGGL(k_merge, dim3((C + 255) / 256), dim3(256), 0, st, gathered, W, C, weight, bias, running_mean,
-                     running_var, momentum, eps, mean, invstd, scale_shift);
-  CHECKED("k_merge");
   const BnTile t = bn_tile(M, C / 4, bn_caps().apply);
   const dim3 g(t.gx, t.gy), b(BN_TPB);
-#define APPLY(R, S) hipLaunchKernelGGL((k_apply<R, S>), g, b, 0, st, x, res, scale_shift, y, M, C / 4, t.TX, t.TY)
+#define APPLY(R, S) hipLaunchKernelGGL((k_apply<R, S>), g, b, 0, st, gathered, W, weight, bias, running_mean, running_var, \
+                                       momentum, eps, mean, invstd, scale_shift, x, res, y, M, C / 4, t.TX, t.TY)
   if (relu && res) APPLY(true, true);
   else if (relu) APPLY(true, false);
   else if (res) APPLY(false, true);
