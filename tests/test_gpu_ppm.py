@@ -313,3 +313,33 @@ def test_lazy_flow_equals_dense(dev, shape, frame, lo, sigma, masked, F1):
         assert torch.equal(u, v)
     if masked:   # logging path: the lazy mask materialises to the same ratio as the dense one
         assert torch.equal(util.calc_mask_ratio(lazy_f[2]), util.calc_mask_ratio(dense_f[2]))
+
+
+def test_regression_loss_module_function_with_lazy_flow(dev):
+    """The public `regression_loss` (PixPro.py:92-247 surface) accepts the LazyFlow handles of --lazy-flow and gives the
+    dense result."""
+    import types
+    from contrast import util
+    from contrast.models.PixPro import regression_loss
+    from recipes import crop_coords, smooth_flow
+    gen = torch.Generator().manual_seed(77)
+    N, C, H, W = 4, 64, 7, 7
+    q = F.normalize(torch.randn(N, C, H, W, generator=gen), dim=1).to(dev)
+    k = F.normalize(torch.randn(N, C, H, W, generator=gen), dim=1).to(dev)
+    cq = crop_coords(N, 128, 96, random.Random(3)).to(dev)
+    ck = cq.clone()
+    ck[:, :4] += 0.02 * torch.randn(N, 4, generator=gen).to(dev)
+    lo_f = smooth_flow((N, 1, 2, 12, 16), 0.5, gen).to(dev)
+    lo_b = (-lo_f).contiguous()
+    size = torch.tensor([96, 128], device=dev)
+    data = [None] * 5 + [[None, lo_f, lo_b], [size.repeat(N, 1), torch.full((N, 1), 2, device=dev)]]
+    base = dict(use_flow_file=True, use_flow_frames=False, flow_cat_norm=False, flow_up=True, alpha1=0.01, alpha2=0.5, debug=False)
+    out = []
+    for lazy in (False, True):
+        ff, fb = util.apply_optical_flow(data, None, types.SimpleNamespace(lazy_flow=lazy, **base))
+        qq = q.clone().requires_grad_(True)
+        loss, (pn, pm) = regression_loss(qq, k, [cq, ff], [ck, fb], 0.7)
+        loss.backward()
+        out.append((loss.item(), pn.clone(), qq.grad.clone()))
+    assert out[0][0] == out[1][0] and torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][2], out[1][2])
+    assert out[0][1].sum() > 0
