@@ -34,14 +34,17 @@ __global__ void __launch_bounds__(TPB) k_normalize(Dirs D, int which, const floa
   float nn = 1.f;
   if (do_norm) {
     float acc = 0.f;
-    if (j < P)
+    if (j < P) {
+#pragma unroll 8
       for (int c = ty; c < C; c += 4) { const float t = s[(size_t)c * P + j]; acc = __builtin_fmaf(t, t, acc); }
+    }
     red[ty][tx] = acc;
     __syncthreads();
     nn = fmaxf(sqrtf(red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx]), 1e-12f);
   }
   if (j >= P) return;
   if (norm && ty == 0) norm[(size_t)b * P + j] = nn;
+#pragma unroll 8
   for (int c = ty; c < C; c += 4) {
     const float t = s[(size_t)c * P + j];
     o[(size_t)c * P + j] = do_norm ? t / nn : t;
@@ -76,19 +79,36 @@ __global__ void __launch_bounds__(256) k_mm(const float* __restrict__ A, const f
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // loader mapping: walk the unit-stride dimension with consecutive threads
+  // loader mapping: walk the unit-stride dimension with consecutive threads; the next 16-deep slab is requested into
+  // registers before the MFMAs of the current one and committed to LDS after them (global latency under the matrix work)
   const bool a_m_fast = q.am == 1, b_n_fast = q.bn == 1;
-  for (int k0 = 0; k0 < q.K; k0 += 16) {
+  int la[4], lb[4];              // LDS slots of this thread's four A / B elements
+  long ga[4], gb[4];             // their global offsets at k0 = 0 (-1: outside M / N)
+  int ka[4], kb[4];              // their k index inside the slab
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int idx = tid + e * 256;                         // 0 .. 1023
+    const int am_ = a_m_fast ? (idx & 63) : (idx >> 4), ak_ = a_m_fast ? (idx >> 6) : (idx & 15);
+    const int bn_ = b_n_fast ? (idx & 63) : (idx >> 4), bk_ = b_n_fast ? (idx >> 6) : (idx & 15);
+    la[e] = ak_ * TS + am_; lb[e] = bk_ * TS + bn_;
+    ka[e] = ak_; kb[e] = bk_;
+    ga[e] = (m0 + am_ < q.M) ? (long)(m0 + am_) * q.am + (long)ak_ * q.ak : -1;
+    gb[e] = (n0 + bn_ < q.N) ? (long)bk_ * q.bk + (long)(n0 + bn_) * q.bn : -1;
+  }
+  float ra[4], rb[4];
+  auto request = [&](int k0) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const int idx = tid + e * 256;                       // 0 .. 1023
-      const int am_ = a_m_fast ? (idx & 63) : (idx >> 4), ak_ = a_m_fast ? (idx >> 6) : (idx & 15);
-      const int bn_ = b_n_fast ? (idx & 63) : (idx >> 4), bk_ = b_n_fast ? (idx >> 6) : (idx & 15);
-      const int gm = m0 + am_, gka = k0 + ak_, gn = n0 + bn_, gkb = k0 + bk_;
-      As[ak_ * TS + am_] = (gm < q.M && gka < q.K) ? a[(long)gm * q.am + (long)gka * q.ak] : 0.f;
-      Bs[bk_ * TS + bn_] = (gn < q.N && gkb < q.K) ? bb[(long)gkb * q.bk + (long)gn * q.bn] : 0.f;
+      ra[e] = (ga[e] >= 0 && k0 + ka[e] < q.K) ? a[ga[e] + (long)k0 * q.ak] : 0.f;
+      rb[e] = (gb[e] >= 0 && k0 + kb[e] < q.K) ? bb[gb[e] + (long)k0 * q.bk] : 0.f;
     }
+  };
+  request(0);
+  for (int k0 = 0; k0 < q.K; k0 += 16) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { As[la[e]] = ra[e]; Bs[lb[e]] = rb[e]; }
     __syncthreads();
+    if (k0 + 16 < q.K) request(k0 + 16);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       float av[2], bv[2];
@@ -202,8 +222,10 @@ __global__ void __launch_bounds__(TPB) k_coldot(const float* __restrict__ A, con
   const float* a = A + (size_t)b * C * P;
   const float* bb = Bm + (size_t)b * C * P;
   float acc = 0.f;
-  if (i < P)
+  if (i < P) {
+#pragma unroll 8
     for (int c = ty; c < C; c += 4) acc = __builtin_fmaf(a[(size_t)c * P + i], bb[(size_t)c * P + i], acc);
+  }
   red[ty][tx] = acc;
   __syncthreads();
   if (ty == 0 && i < P) tcol[(size_t)b * P + i] = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
