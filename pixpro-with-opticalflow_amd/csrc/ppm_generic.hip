@@ -95,6 +95,12 @@ __global__ void __launch_bounds__(256) k_mm(const float* __restrict__ A, const f
     ga[e] = (m0 + am_ < q.M) ? (long)(m0 + am_) * q.am + (long)ak_ * q.ak : -1;
     gb[e] = (n0 + bn_ < q.N) ? (long)bk_ * q.bk + (long)(n0 + bn_) * q.bn : -1;
   }
+  // 16 x 16 sub-tiles that lie entirely outside M x N (P = 196 = 12.25 tiles) issue no MFMA (wave-uniform)
+  bool live[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) live[i][j] = (m0 + wm + 16 * i < q.M) && (n0 + wn + 16 * j < q.N);
   float ra[4], rb[4];
   auto request = [&](int k0) {
 #pragma unroll
@@ -120,7 +126,8 @@ __global__ void __launch_bounds__(256) k_mm(const float* __restrict__ A, const f
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = mfma16(av[i], bv[j], acc[i][j]);
+        for (int j = 0; j < 2; ++j)
+          if (live[i][j]) acc[i][j] = mfma16(av[i], bv[j], acc[i][j]);
     }
     __syncthreads();
   }
@@ -200,7 +207,8 @@ __global__ void k_count(const float* __restrict__ M, float* __restrict__ cnt, fl
   const int b = blockIdx.x;
   const float* m = M + (size_t)b * P * P;
   float acc = 0.f;
-  for (int e = threadIdx.x; e < P * P; e += TPB) acc += m[e];
+#pragma unroll 8
+  for (int e = threadIdx.x; e < P * P; e += TPB) acc += m[e];      // 0/1 values: the sum is exact in any order
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
@@ -275,15 +283,25 @@ __global__ void k_dy(float* __restrict__ G, const float* __restrict__ Yh, const 
 }
 
 // dSs[b,i,j] = dA[i,j]*D[i,j] + dA[j,i]*D[j,i]
-__global__ void k_symm(const float* __restrict__ dA, const float* __restrict__ Dm, float* __restrict__ out, int B,
-                       int P) {
-  const size_t idx = (size_t)blockIdx.x * TPB + threadIdx.x;
-  if (idx >= (size_t)B * P * P) return;
-  const int b = (int)(idx / ((size_t)P * P));
-  const int r = (int)(idx % ((size_t)P * P)), i = r / P, j = r % P;
+// 32 x 32 tiles: tile (ti, tj) of E = dA o D is added to the LDS-transposed tile (tj, ti), so both reads are row-wise.
+__global__ void __launch_bounds__(256) k_symm(const float* __restrict__ dA, const float* __restrict__ Dm,
+                                              float* __restrict__ out, int B, int P) {
+  __shared__ float tr[32][33];
+  const int b = blockIdx.z, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8
+  const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
   const size_t base = (size_t)b * P * P;
-  out[idx] = dA[base + (size_t)i * P + j] * Dm[base + (size_t)i * P + j] +
-             dA[base + (size_t)j * P + i] * Dm[base + (size_t)j * P + i];
+  for (int r = ty; r < 32; r += 8) {                                             // E[j0 + r][i0 + tx] -> tr[r][tx]
+    const int jj = j0 + r, ii = i0 + tx;
+    tr[r][tx] = (jj < P && ii < P) ? dA[base + (size_t)jj * P + ii] * Dm[base + (size_t)jj * P + ii] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int i = i0 + r, j = j0 + tx;
+    if (i < P && j < P) {
+      const size_t o = base + (size_t)i * P + j;
+      out[o] = dA[o] * Dm[o] + tr[tx][r];
+    }
+  }
 }
 
 // out[b,c,j] = (T - Xh*s_j)/n_j written to the per-direction gradient buffer `which_out`
@@ -427,7 +445,8 @@ int run_generic(const pixpro_problem& pb, const pixpro_dir* dirs, float* loss_n,
   LAUNCH_G(k_coldot, vh, T, scol, B, C, P);
   LAUNCH(k_project, B * R, D, 1, nullptr, T, vh, scol, nv, B, N, C, P);   // dv
   GRAM(G, vh, M);                       // dA (in M buffer)
-  LAUNCH(k_symm, B * Q, M, Dm, dS, B, P);
+  hipLaunchKernelGGL(k_symm, dim3((P + 31) / 32, (P + 31) / 32, B), dim3(256), 0, st, M, Dm, dS, B, P);
+  if (int e = check_launch("k_symm")) return e;
   APPLY(xh, dS, T, 1);                  // dXh = xh * dSs
   LAUNCH_G(k_coldot, xh, T, scol, B, C, P);
   LAUNCH(k_project, B * R, D, 0, nullptr, T, xh, scol, nx, B, N, C, P);   // dx
@@ -471,7 +490,8 @@ int run_featprop(const pixpro_problem& pb, const float* x, const float* v, const
   LAUNCH_G(k_coldot, vh, T, scol, B, C, P);
   LAUNCH(k_project, B * R, D, 1, nullptr, T, vh, scol, nv, B, N, C, P);
   GRAM(G, vh, M);
-  LAUNCH(k_symm, B * Q, M, Dm, dS, B, P);
+  hipLaunchKernelGGL(k_symm, dim3((P + 31) / 32, (P + 31) / 32, B), dim3(256), 0, st, M, Dm, dS, B, P);
+  if (int e = check_launch("k_symm")) return e;
   APPLY(xh, dS, T, 1);
   LAUNCH_G(k_coldot, xh, T, scol, B, C, P);
   LAUNCH(k_project, B * R, D, 0, nullptr, T, xh, scol, nx, B, N, C, P);
