@@ -212,14 +212,9 @@ class RAFT(nn.Module):
     def __init__(self, args):
         super().__init__()
         self.args = args
-        if "small" not in args:
-            args.small = False
-        if "dropout" not in args:
-            args.dropout = 0
-        if "alternate_corr" not in args:
-            args.alternate_corr = False
-        if "mixed_precision" not in args:
-            args.mixed_precision = False
+        for name, default in (("small", False), ("dropout", 0), ("alternate_corr", False), ("mixed_precision", False)):
+            if not hasattr(args, name):          # the reference tests `name in args`; any attribute container works here
+                setattr(args, name, default)
         if args.alternate_corr:
             raise NotImplementedError("alternate_corr: the volume is kept resident on MI355X (flow/corr.py)")
         if args.mixed_precision:

@@ -1,6 +1,6 @@
 """RAFT(-small) inference at the production frame size on one MI355X: time per frame pair, and the windowed correlation
 lookup as one HIP launch (contrast/flow/corr.py) against the reference's formulation in torch ops (4 x grid_sample +
-temporaries per iteration, oracle/raft_oracle.py run on the device).  usage: python tools/raft_bench.py [batch] [--basic]"""
+temporaries per iteration, restated below with torch ops on the device).  usage: python tools/raft_bench.py [batch] [--basic]"""
 import argparse
 import os
 import sys
@@ -14,7 +14,26 @@ import torch  # noqa: E402
 from contrast.miopen_tuning import use_shipped_db  # noqa: E402
 use_shipped_db()
 from contrast.flow import RAFT, corr  # noqa: E402
-from oracle import raft_oracle as R  # noqa: E402  (timed beside the product as the reference's formulation)
+
+
+def torch_ops_lookup(pyramid, coords, radius):
+    """The reference's per-iteration formulation (contrast/flow/corr.py:29-50) in torch ops on the device: per level
+    linspace/meshgrid/add, one grid_sample, then view/cat/permute/contiguous."""
+    import torch.nn.functional as F
+    r = radius
+    coords = coords.permute(0, 2, 3, 1)
+    B, h1, w1, _ = coords.shape
+    out = []
+    for i, vol in enumerate(pyramid):
+        d = torch.linspace(-r, r, 2 * r + 1, device=coords.device)
+        delta = torch.stack(torch.meshgrid(d, d, indexing="ij"), dim=-1)
+        lvl = coords.reshape(B * h1 * w1, 1, 1, 2) / 2 ** i + delta.view(1, 2 * r + 1, 2 * r + 1, 2)
+        H, W = vol.shape[-2:]
+        xg, yg = lvl.split([1, 1], dim=-1)
+        grid = torch.cat([2 * xg / (W - 1) - 1, 2 * yg / (H - 1) - 1], dim=-1)
+        out.append(F.grid_sample(vol, grid, align_corners=True).view(B, h1, w1, -1))
+    return torch.cat(out, dim=-1).permute(0, 3, 1, 2).contiguous().float()
+
 from recipes import raft_images, raft_state_dict  # noqa: E402
 
 
@@ -46,8 +65,8 @@ def main():
         coords = torch.stack(torch.meshgrid(torch.arange(W // 8, device=dev), torch.arange(H // 8, device=dev), indexing="xy"), 0)
         coords = coords.float()[None].repeat(B, 1, 1, 1) + 1.7
         t_hip = timed(lambda: corr.lookup(pyr, coords, r), 10)
-        t_ref = timed(lambda: R.corr_lookup(pyr, coords, r), 10)
-        diff = (corr.lookup(pyr, coords, r) - R.corr_lookup(pyr, coords, r)).abs().max().item()
+        t_ref = timed(lambda: torch_ops_lookup(pyr, coords, r), 10)
+        diff = (corr.lookup(pyr, coords, r) - torch_ops_lookup(pyr, coords, r)).abs().max().item()
     vol_gb = sum(p.numel() for p in pyr) * 4 / 1e9
     out_bytes = B * 4 * (2 * r + 1) ** 2 * (H // 8) * (W // 8) * 4
     print(f"RAFT{'-small' if small else ''} {H}x{W}, batch {B}, 12 iterations, fp32")
