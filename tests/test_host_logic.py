@@ -166,3 +166,25 @@ def test_accuracy_helper():
     out = torch.tensor([[0.1, 0.7, 0.2], [0.8, 0.1, 0.1], [0.2, 0.3, 0.5]])
     top1, top2 = util.accuracy(out, torch.tensor([1, 0, 1]), topk=(1, 2))
     assert abs(top1.item() - 200.0 / 3) < 1e-4 and top2.item() == 100.0
+
+
+def test_product_and_tools_never_touch_the_oracle():
+    """oracle/ is test infrastructure: nothing under the package or tools/ may import it, and the product must fail
+    loudly without the HIP library instead of falling back."""
+    import re
+    from conftest import PKG, ROOT
+    pat = re.compile(r"^\s*(from|import)\s+oracle\b|import_module\(.oracle", re.M)
+    offenders = []
+    for base in (PKG, os.path.join(ROOT, "tools")):
+        for dirpath, _, files in os.walk(base):
+            for f in files:
+                if f.endswith(".py") and pat.search(open(os.path.join(dirpath, f)).read()):
+                    offenders.append(os.path.join(dirpath, f))
+    assert offenders == []
+    from contrast import _native
+    saved, _native._lib, _native.LIB_PATH = (_native._lib, _native.LIB_PATH), None, "/nonexistent/libpixpro_hip.so"
+    try:
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            _native.load()
+    finally:
+        _native._lib, _native.LIB_PATH = saved
