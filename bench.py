@@ -399,6 +399,8 @@ def main():
                                    f"nframe={a.n_frames}, 720x1280 frames, file-mode flow (flow_up, alpha1=0.01, alpha2=0.5), "
                                    f"p=2, transform_layer=1, LARS, fp32",
                        "batch_norm": "fused HIP SyncBN+ReLU" if a.fused_bn else "torch (Sync)BatchNorm",
+                       "miopen": "immediate mode + find-db recorded on MI355X (pixpro-with-opticalflow_amd/miopen_db)"
+                                 if tuned else "immediate mode, library heuristics",
                        "flow_mode": "lazy (flow + mask evaluated at the loss sample points)" if a.lazy_flow else "dense",
                        "per_gpu_batch": a.batch, "global_batch": a.batch * world,
                        "parallelism": f"dp{world}" if world > 1 else "single", "final_loss": round(final_loss, 5),
