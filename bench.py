@@ -128,7 +128,7 @@ class BnAudit:
         "pixpro_bn_stats": (1, 2, lambda a: 1),
         "pixpro_bn_apply": (11, 12, lambda a: 2 + (a[3] is not None)),
         "pixpro_bn_backward_reduce": (7, 8, lambda a: 2 + (a[6] != 0 and a[3] is None)),
-        "pixpro_bn_backward_apply": (10, 11, lambda a: 3 + (a[9] != 0 and a[3] is None) + (a[13] is not None)),
+        "pixpro_bn_backward_apply": (12, 13, lambda a: 3 + (a[11] != 0 and a[3] is None) + (a[15] is not None)),
     }
 
     def __init__(self):

@@ -215,12 +215,13 @@ int pixpro_bn_backward_reduce(const float* dy, const float* x, const float* y, c
                               const float* mean, const float* invstd, int32_t relu, int64_t rows, int32_t C,
                               void* workspace, size_t workspace_bytes, float* sums,
                               float* grad_weight, float* grad_bias, void* stream);
-/* sums: totals over all ranks, count: total rows over all ranks.
+/* sums: totals over all ranks.  counts[r * count_stride], r < world: the rows of every rank as exchanged in the forward
+ * pass (pass gathered + 2C with count_stride = 2C+1); count = their sum, ranks may hold different batch sizes.
  * dx = (dz - sum_dz/count - (x-mean)*invstd^2*sum_dz_xmu/count) * invstd * weight;  dresidual = dz (nullable). */
 int pixpro_bn_backward_apply(const float* dy, const float* x, const float* y, const float* scale_shift,
-                             const float* mean, const float* invstd, const float* weight, const float* sums, double count,
-                             int32_t relu, int64_t rows, int32_t C, float* dx, float* dresidual,
-                             void* stream);
+                             const float* mean, const float* invstd, const float* weight, const float* sums,
+                             const float* counts, int32_t world, int64_t count_stride, int32_t relu, int64_t rows,
+                             int32_t C, float* dx, float* dresidual, void* stream);
 
 #ifdef __cplusplus
 }

@@ -67,8 +67,8 @@ SIGNATURES = {
                                        _vp, _vp, _vp, _vp, _vp]),
     "pixpro_bn_backward_reduce": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _vp, _sz, _vp, _vp,
                                                  _vp, _vp]),
-    "pixpro_bn_backward_apply": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _i32, _i64, _i32, _vp,
-                                                _vp, _vp]),
+    "pixpro_bn_backward_apply": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i64, _i32,
+                                                _vp, _vp, _vp]),
 }
 
 _lib = None

@@ -14,6 +14,8 @@ the streaming kernels of csrc/sync_bn.hip:
 Parameter / buffer names are those of `nn.BatchNorm2d` (`weight, bias, running_mean, running_var, num_batches_tracked`),
 so checkpoints load either way.  Activations must be channels_last (the layout the encoders run in); CPU tensors raise.
 """
+import ctypes
+
 import torch
 import torch.distributed as dist
 import torch.nn as nn
@@ -79,13 +81,13 @@ class _FusedBN(torch.autograd.Function):
                 nv.ptr(mean), nv.ptr(invstd), nv.ptr(scale_shift), nv.stream())
         # the ReLU decision is recomputed from x in backward unless a residual entered it (then the output is needed)
         ctx.save_for_backward(x, y if (relu and residual is not None) else None, weight, mean, invstd,
-                              scale_shift if (relu and residual is None) else None)
+                              scale_shift if (relu and residual is None) else None, gathered)
         ctx.meta = (rows, C, bool(relu), residual is not None, group, world)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, y, weight, mean, invstd, scale_shift = ctx.saved_tensors
+        x, y, weight, mean, invstd, scale_shift, gathered = ctx.saved_tensors
         rows, C, relu, has_res, group, world = ctx.meta
         if dy.dim() == 4 and not dy.is_contiguous(memory_format=torch.channels_last) or dy.dim() == 2 and not dy.is_contiguous():
             dy = dy.contiguous(memory_format=torch.channels_last) if dy.dim() == 4 else dy.contiguous()
@@ -108,10 +110,11 @@ class _FusedBN(torch.autograd.Function):
         if dx is None and dres is not None:
             dx = torch.empty_like(x)
         if dx is not None:
-            # per-rank batches are equal (the reference's loader drops the last partial batch), so count = world * rows
+            # the total row count is the sum of what the ranks exchanged in forward (element 2C of each packed record)
+            counts = ctypes.c_void_p(gathered.data_ptr() + 2 * C * 4)
             nv.call("pixpro_bn_backward_apply", nv.ptr(dy), nv.ptr(x), nv.ptr(y), nv.ptr(scale_shift), nv.ptr(mean),
-                    nv.ptr(invstd), nv.ptr(weight), nv.ptr(sums), float(rows) * world, int(relu), rows, C, nv.ptr(dx), nv.ptr(dres),
-                    nv.stream())
+                    nv.ptr(invstd), nv.ptr(weight), nv.ptr(sums), counts, world, 2 * C + 1, int(relu), rows, C,
+                    nv.ptr(dx), nv.ptr(dres), nv.stream())
         return dx, gw, gb, dres, None, None, None, None, None, None
 
 

@@ -78,8 +78,8 @@ int run_bn_bwd_reduce(const float* dy, const float* x, const float* y, const flo
                       const float* invstd, int relu, int64_t M, int C, float* ws, float* sums, float* grad_weight,
                       float* grad_bias, hipStream_t st);
 int run_bn_bwd_apply(const float* dy, const float* x, const float* y, const float* scale_shift, const float* mean,
-                     const float* invstd, const float* weight, const float* sums, double count, int relu, int64_t M, int C,
-                     float* dx, float* dres, hipStream_t st);
+                     const float* invstd, const float* weight, const float* sums, const float* counts, int world,
+                     int64_t count_stride, int relu, int64_t M, int C, float* dx, float* dres, hipStream_t st);
 
 namespace {
 
@@ -321,17 +321,19 @@ int pixpro_bn_backward_reduce(const float* dy, const float* x, const float* y, c
 }
 
 int pixpro_bn_backward_apply(const float* dy, const float* x, const float* y, const float* scale_shift,
-                             const float* mean, const float* invstd, const float* weight, const float* sums, double count,
-                             int32_t relu, int64_t rows, int32_t C, float* dx, float* dresidual, void* stream) {
+                             const float* mean, const float* invstd, const float* weight, const float* sums,
+                             const float* counts, int32_t world, int64_t count_stride, int32_t relu, int64_t rows,
+                             int32_t C, float* dx, float* dresidual, void* stream) {
   if (!dy || !x || !mean || !invstd || !sums || !dx) return bad("null pointer");
   if (relu && !y && !scale_shift) return bad("relu backward needs the forward output y or the forward's scale_shift");
   if ((uintptr_t)scale_shift & 15) return bad("scale_shift must be 16-byte aligned");
-  if (!(count >= 1.0)) return bad("count must be >= 1");
+  if (!counts || world < 1 || count_stride < 1) return bad("counts / world / count_stride: the ranks' row counts are required");
   if (int e = bn_shape_ok(rows, C)) return e;
   if (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)y | (uintptr_t)dx | (uintptr_t)dresidual | (uintptr_t)mean |
        (uintptr_t)invstd | (uintptr_t)weight | (uintptr_t)sums) & 15)
     return bad("batch norm backward operands must be 16-byte aligned");
-  return run_bn_bwd_apply(dy, x, y, scale_shift, mean, invstd, weight, sums, count, relu, rows, C, dx, dresidual,
+  return run_bn_bwd_apply(dy, x, y, scale_shift, mean, invstd, weight, sums, counts, world, count_stride, relu, rows, C, dx,
+                          dresidual,
                           (hipStream_t)stream);
 }
 

@@ -273,7 +273,8 @@ __global__ void __launch_bounds__(BN_TPB)
 k_bwd_apply(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ y,
             const float* __restrict__ scale_shift, const float* __restrict__ mean, const float* __restrict__ invstd,
             const float* __restrict__ weight,
-            const float* __restrict__ sums, float inv_n, float* __restrict__ dx, float* __restrict__ dres, int64_t M,
+            const float* __restrict__ sums, const float* __restrict__ counts, int W, int64_t cstride,
+            float* __restrict__ dx, float* __restrict__ dres, int64_t M,
             int C4, int TX, int TY) {
   const int cc = blockIdx.x * TX + (threadIdx.x & (TX - 1));
   const int64_t C = (int64_t)C4 * 4;
@@ -282,6 +283,10 @@ k_bwd_apply(const float* __restrict__ dy, const float* __restrict__ x, const flo
   const float4 sd = ld4(sums, cc), sx = ld4(sums + C, cc);
   float4 sc = mu, sf = mu;
   if (MODE == 2) { sc = ld4(scale_shift, cc); sf = ld4(scale_shift + C, cc); }
+  // total rows over all ranks: the counts the ranks exchanged in the forward pass (they may differ between ranks)
+  double n_all = 0.0;
+  for (int r = 0; r < W; ++r) n_all += (double)counts[r * cstride];
+  const float inv_n = (float)(1.0 / n_all);
   // dx = dz * a + (x - mean) * b + c  per channel
   float4 a, b, c;
   a.x = is.x * w.x; a.y = is.y * w.y; a.z = is.z * w.z; a.w = is.w * w.w;
@@ -361,13 +366,12 @@ int run_bn_bwd_reduce(const float* dy, const float* x, const float* y, const flo
 }
 
 int run_bn_bwd_apply(const float* dy, const float* x, const float* y, const float* scale_shift, const float* mean,
-                     const float* invstd, const float* weight, const float* sums, double count, int relu, int64_t M, int C,
-                     float* dx, float* dres, hipStream_t st) {
+                     const float* invstd, const float* weight, const float* sums, const float* counts, int world,
+                     int64_t count_stride, int relu, int64_t M, int C, float* dx, float* dres, hipStream_t st) {
   const BnTile t = bn_tile(M, C / 4, bn_caps().bwd_apply);
   const dim3 g(t.gx, t.gy), b(BN_TPB);
-  const float inv_n = (float)(1.0 / count);
 #define BAPPLY(MD, S) hipLaunchKernelGGL((k_bwd_apply<MD, S>), g, b, 0, st, dy, x, y, scale_shift, mean, invstd, weight, \
-                                         sums, inv_n, dx, dres, M, C / 4, t.TX, t.TY)
+                                         sums, counts, world, count_stride, dx, dres, M, C / 4, t.TX, t.TY)
   const int mode = mask_mode(relu, scale_shift);
   if (dres) { if (mode == 0) BAPPLY(0, true); else if (mode == 1) BAPPLY(1, true); else BAPPLY(2, true); }
   else { if (mode == 0) BAPPLY(0, false); else if (mode == 1) BAPPLY(1, false); else BAPPLY(2, false); }

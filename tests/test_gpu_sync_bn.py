@@ -129,8 +129,7 @@ def _rank(rank, world, port, path):
     from contrast.sync_bn import FusedSyncBatchNorm
     dev = torch.device("cuda:0")
     d = torch.load(path)
-    n = d["x"].shape[0] // world
-    sl = slice(rank * n, (rank + 1) * n)
+    sl = slice(0, 7) if rank == 0 else slice(7, d["x"].shape[0])      # unequal shards: 7 and 5 samples
     bn = FusedSyncBatchNorm(d["x"].shape[1]).to(dev).train()
     with torch.no_grad():
         bn.weight.copy_(d["w"]); bn.bias.copy_(d["b"])
@@ -145,13 +144,13 @@ def _rank(rank, world, port, path):
 
 
 def test_two_ranks_equal_one_process_on_the_whole_batch(dev, tmp_path):
-    """The SyncBN contract: statistics and input gradients are those of the global batch; parameter gradients are the
-    local sums (DDP averages them afterwards)."""
+    """The SyncBN contract: statistics and input gradients are those of the global batch - also when the ranks hold
+    different numbers of samples; parameter gradients are the local sums (DDP averages them afterwards)."""
     g = torch.Generator().manual_seed(11)
     shape = (12, 128, 9, 9)
     d = dict(x=torch.randn(shape, generator=g) * 2 + 1, res=torch.randn(shape, generator=g), dy=torch.randn(shape, generator=g),
              w=torch.rand(128, generator=g) + 0.5, b=torch.randn(128, generator=g))
-    d["x"][6:] += 0.7                                   # the two shards have different statistics
+    d["x"][7:] += 0.7                                   # the two shards have different statistics (and sizes: 7 + 5)
     path = str(tmp_path / "case.pt")
     torch.save(d, path)
     mp.spawn(_rank, args=(2, _free_port(), path), nprocs=2, join=True)
