@@ -60,6 +60,9 @@ def parse():
     ap.add_argument("--no-fused-bn", dest="fused_bn", action="store_false",
                     help="torch's (Sync)BatchNorm + ReLU + add instead of the HIP (Sync)BatchNorm with ReLU / residual add "
                          "folded in (default: fused; same statistics exchange, tests/test_gpu_sync_bn.py)")
+    ap.add_argument("--no-overlap-momentum", dest="overlap_momentum", action="store_false",
+                    help="run the key (momentum) branch after the online branch on the same stream (default: on a second HIP "
+                         "stream, concurrently)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-flow-images", type=int, default=8)
     ap.add_argument("--no-channels-last", dest="channels_last", action="store_false",
@@ -86,6 +89,8 @@ def model_args(a, world):
         argv.append("--lazy-flow")
     if a.fused_bn:
         argv.append("--fused-bn")
+    if a.overlap_momentum:
+        argv.append("--overlap-momentum")
     args = option.parse_option(argv=argv)
     args.num_instances = 70000
     return args
@@ -399,6 +404,7 @@ def main():
                                    f"nframe={a.n_frames}, 720x1280 frames, file-mode flow (flow_up, alpha1=0.01, alpha2=0.5), "
                                    f"p=2, transform_layer=1, LARS, fp32",
                        "batch_norm": "fused HIP SyncBN+ReLU" if a.fused_bn else "torch (Sync)BatchNorm",
+                       "key_branch": "second HIP stream" if a.overlap_momentum else "same stream",
                        "miopen": "immediate mode + find-db recorded on MI355X (pixpro-with-opticalflow_amd/miopen_db)"
                                  if tuned else "immediate mode, library heuristics",
                        "flow_mode": "lazy (flow + mask evaluated at the loss sample points)" if a.lazy_flow else "dense",

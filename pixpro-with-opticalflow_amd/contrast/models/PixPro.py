@@ -104,6 +104,8 @@ class PixPro(BaseModel):
         self.pixpro_transform_layer = args.pixpro_transform_layer
         self.pixpro_ins_loss_weight = args.pixpro_ins_loss_weight
         self.output_root = getattr(args, "output_dir", None)
+        self.overlap_momentum = bool(getattr(args, "overlap_momentum", False))
+        self._side_stream = None
 
         self.encoder = base_encoder(head_type="early_return")
         c5 = getattr(self.encoder, "out_channels", 2048)
@@ -176,14 +178,7 @@ class PixPro(BaseModel):
     def regression_loss(self, x, y):
         return -2. * torch.einsum('nc, nc->n', [x, y]).mean()
 
-    def forward(self, im_1, im_2, coord1, coord2, is_update_momentum=True):
-        feat_1 = self.encoder(im_1)
-        proj_1 = self.projector(feat_1)
-        feat_2 = self.encoder(im_2)
-        proj_2 = self.projector(feat_2)
-        val_1 = self.value_transform(proj_1)
-        val_2 = self.value_transform(proj_2)
-
+    def _momentum_passes(self, im_1, im_2, is_update_momentum):
         with torch.no_grad():
             if is_update_momentum:
                 self._momentum_update_key_encoder()
@@ -191,6 +186,33 @@ class PixPro(BaseModel):
             key_1 = self.projector_k(feat_1_ng)          # normalised inside the kernel (:403)
             feat_2_ng = self.encoder_k(im_2)
             key_2 = self.projector_k(feat_2_ng)
+        return key_1, key_2, feat_1_ng, feat_2_ng
+
+    def forward(self, im_1, im_2, coord1, coord2, is_update_momentum=True):
+        overlap = self.overlap_momentum and im_1.is_cuda
+        if overlap:
+            # the key branch (EMA update + two no-grad passes) depends on nothing the online branch produces: it runs on a
+            # second stream, filling the CUs the small late-stage kernels leave idle and, with several ranks, the waits on the
+            # SyncBN collectives.  Collectives are still issued in host program order, identical on every rank.
+            main = torch.cuda.current_stream()
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream(device=im_1.device)
+            side = self._side_stream
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                key_1, key_2, feat_1_ng, feat_2_ng = self._momentum_passes(im_1, im_2, is_update_momentum)
+        feat_1 = self.encoder(im_1)
+        proj_1 = self.projector(feat_1)
+        feat_2 = self.encoder(im_2)
+        proj_2 = self.projector(feat_2)
+        val_1 = self.value_transform(proj_1)
+        val_2 = self.value_transform(proj_2)
+        if overlap:
+            main.wait_stream(side)
+            for t in (key_1, key_2, feat_1_ng, feat_2_ng):
+                t.record_stream(main)
+        else:
+            key_1, key_2, feat_1_ng, feat_2_ng = self._momentum_passes(im_1, im_2, is_update_momentum)
 
         c1, c2, flow_fwd, size, mask_fwd = _unpack(coord1, coord2)
         _, _, flow_bwd, _, mask_bwd = _unpack(coord2, coord1)

@@ -85,6 +85,8 @@ _FLAGS = [
     (("--lazy-flow",), dict(action="store_true", help="evaluate flow chain + consistency mask inside the loss kernel at "
                                                       "its sample points instead of preparing dense tensors (same results)")),
     (("--channels-last",), dict(action="store_true")),
+    (("--overlap-momentum",), dict(action="store_true", help="run the key (momentum) branch on a second HIP stream, "
+                                                             "concurrently with the online branch")),
     (("--fused-bn",), dict(action="store_true", help="HIP (Sync)BatchNorm with the ReLU / residual add folded in "
                                                      "(needs --channels-last)")),
 ]

@@ -249,3 +249,36 @@ def test_train_step_fused_bn_and_checkpoint_interchange(dev, tmp_path):
     with torch.no_grad():
         a, b = model.encoder(im), model2.encoder(im)
     assert torch.allclose(a, b, rtol=1e-4, atol=1e-5)
+
+
+def test_overlapped_momentum_branch_gives_the_same_step(dev):
+    """--overlap-momentum only changes WHERE the key branch runs (a second stream): after three steps the loss, the
+    positive counts and the EMA-updated key weights are those of the sequential schedule."""
+    import main_pretrain
+    from contrast import option
+    from contrast.lr_scheduler import get_scheduler
+    from contrast.synthetic import make_batch
+    base = ["--model", "PixPro", "--arch", "resnet18", "--synthetic", "--use_flow", "--use_flow_file", "--flow_up",
+            "--alpha1", "0.01", "--alpha2", "0.5", "--n-frames", "2", "--optimizer", "lars", "--base-lr", "1.0",
+            "--weight-decay", "1e-5", "--amp-opt-level", "O0", "--pixpro-p", "2", "--pixpro-transform-layer", "1",
+            "--batch-size", "8", "--epochs", "2", "--warmup-epoch", "0", "--head-type", "early_return", "--fused-bn",
+            "--channels-last", "--pixpro-ins-loss-weight", "0.5"]
+    data = make_batch(8, image_size=64, n_frames=2, frame_hw=(96, 128), device=dev, sigma=0.8, channels_last=True)
+    out = []
+    for extra in ([], ["--overlap-momentum"]):
+        args = option.parse_option(argv=base + extra)
+        args.num_instances = 32
+        torch.manual_seed(0)
+        model, opt = main_pretrain.build_model(args, dev)
+        assert model.overlap_momentum == bool(extra)
+        sched = get_scheduler(opt, 4, args)
+        model.train()
+        for _ in range(3):
+            loss, pos, _ = main_pretrain.train_step(model, opt, sched, data, args)
+        torch.cuda.synchronize()
+        out.append((loss.item(), pos[0][0].clone(), model.encoder_k.conv1.weight.detach().clone(),
+                    model.encoder_k.bn1.running_mean.detach().clone()))
+    assert abs(out[0][0] - out[1][0]) <= 1e-4 * max(1.0, abs(out[0][0]))
+    assert torch.equal(out[0][1], out[1][1])
+    assert torch.allclose(out[0][2], out[1][2], rtol=1e-4, atol=1e-6)
+    assert torch.allclose(out[0][3], out[1][3], rtol=1e-4, atol=1e-6)
