@@ -381,6 +381,9 @@ def main():
                 kernels[extra] = {"bound": "hbm", "achieved": round(nbytes / t / 1e9, 1), "peak": HBM_PEAK / 1e9,
                                   "unit": "GB/s", "frac": round(nbytes / t / HBM_PEAK, 4), "traffic": None,
                                   "ms_per_launch": round(ms[extra], 4), "algorithmic_bytes_per_launch": nbytes}
+                if extra == "ema_update" and a.overlap_momentum:
+                    kernels[extra]["note"] = ("runs on the second stream next to the online branch's kernels: the event "
+                                              "pair spans shared-GPU time (0.125 ms = 3.2 TB/s alone, --no-overlap-momentum)")
         if bn:
             n_l = sum(v[0] for v in bn.values())
             t_ms = sum(v[1] for v in bn.values())
