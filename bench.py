@@ -389,7 +389,8 @@ def main():
             t_ms = sum(v[1] for v in bn.values())
             nb = sum(v[2] for v in bn.values())
             kernels["batch_norm"] = {"bound": "hbm", "achieved": round(nb / (t_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK / 1e9,
-                                     "unit": "GB/s", "frac": round(nb / (t_ms * 1e-3) / HBM_PEAK, 4), "traffic": None,
+                                     "unit": "GB/s", "frac": round(nb / (t_ms * 1e-3) / HBM_PEAK, 4),
+                                     "traffic": pmc_traffic("batch_norm", a) if a.arch == "resnet50" else None,
                                      "ms_per_step": round(t_ms, 3), "launch_pairs_per_step": n_l,
                                      "algorithmic_bytes_per_step": int(nb),
                                      "by_call": {k: {"n": v[0], "ms": round(v[1], 3),
