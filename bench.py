@@ -60,10 +60,15 @@ def parse():
     ap.add_argument("--no-fused-bn", dest="fused_bn", action="store_false",
                     help="torch's (Sync)BatchNorm + ReLU + add instead of the HIP (Sync)BatchNorm with ReLU / residual add "
                          "folded in (default: fused; same statistics exchange, tests/test_gpu_sync_bn.py)")
-    ap.add_argument("--no-overlap-momentum", dest="overlap_momentum", action="store_false",
-                    help="run the key (momentum) branch after the online branch on the same stream (default: on a second HIP "
-                         "stream, concurrently)")
+    ap.add_argument("--overlap-momentum", choices=("auto", "on", "off"), default="auto",
+                    help="key (momentum) branch on a second HIP stream next to the online branch.  auto = on with one rank, off "
+                         "with several: every SyncBN collective of a process goes through ProcessGroupNCCL's one internal stream "
+                         "in host order, so with >1 rank the two branches would serialise at every layer anyway")
+    ap.add_argument("--no-overlap-momentum", dest="overlap_momentum", action="store_const", const="off")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="launcher check without a GPU: start the ranks, form the process group over gloo on the CPU, run the "
+                         "barrier / max-over-ranks timing reduction around an empty timed region, print the JSON line and stop")
     ap.add_argument("--cpu-flow-images", type=int, default=8)
     ap.add_argument("--no-channels-last", dest="channels_last", action="store_false",
                     help="keep NCHW activations (default: channels_last, which MIOpen's fp32 implicit-GEMM kernels prefer)")
@@ -89,6 +94,7 @@ def model_args(a, world):
         argv.append("--lazy-flow")
     if a.fused_bn:
         argv.append("--fused-bn")
+    a.overlap_momentum = a.overlap_momentum == "on" or (a.overlap_momentum == "auto" and world == 1)
     if a.overlap_momentum:
         argv.append("--overlap-momentum")
     args = option.parse_option(argv=argv)
@@ -266,16 +272,109 @@ def cpu_cfg1_step():
         ops.ppm_loss, pixpro_mod.ema_update = saved
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(a):
+    """`python bench.py --gpus N` with no torch.distributed.run around it: start one child process per GPU (the reference's
+    launch is one MPI rank per GPU, main_pretrain_mpirun.py:17-49) with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the
+    environment, pass rank 0's JSON line through and exit non-zero when any rank fails.  This parent never touches the GPU
+    (torch.cuda.device_count() does not initialise it), so nothing that has initialised HIP is ever replaced or forked."""
+    import subprocess
+    rehearsal = os.environ.get("PIXPRO_REHEARSAL") == "1"
+    have = torch.cuda.device_count()
+    if have < a.gpus and not rehearsal and not a.dry_launch:
+        sys.exit(f"[bench] --gpus {a.gpus} but only {have} GPU(s) are visible (PIXPRO_REHEARSAL=1 shares one GPU over gloo)")
+    port = _free_port()
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PIXPRO_LAUNCHED_BY="bench.py")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", str(max(1, len(os.sched_getaffinity(0)) // a.gpus)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for q in pending:      # a dead rank leaves the others waiting in a collective: stop them (exact PIDs)
+                        q.terminate()
+            time.sleep(0.2)
+    except KeyboardInterrupt:
+        rc = 130
+        for p in procs:
+            p.terminate()
+    for p in procs:
+        try:
+            p.wait(timeout=30)
+        except subprocess.TimeoutExpired:
+            p.kill()
+    if rc:
+        print(f"[bench] a rank failed (exit code {rc})", file=sys.stderr, flush=True)
+    sys.exit(rc)
+
+
+def dry_launch(a, world, rank):
+    """The N>1 control flow of main() with nothing in the timed region (tests/test_bench_launcher.py)."""
+    seed = 1234 + rank
+    comm = None
+    if os.environ.get("PIXPRO_TEST_FAIL_RANK") == str(rank):
+        sys.exit(7)
+    if world > 1:
+        dist.init_process_group(backend="gloo", init_method="env://")
+        ones = torch.ones(1)
+        dist.all_reduce(ones)
+        seeds = [None] * world
+        dist.all_gather_object(seeds, seed)
+        comm = {"world": dist.get_world_size(), "backend": dist.get_backend(), "allreduce_of_ones": int(ones.item()),
+                "seeds": seeds, "launcher": os.environ.get("PIXPRO_LAUNCHED_BY", "torch.distributed.run")}
+        dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (rank + 1))
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    if rank == 0:
+        print(json.dumps({"dry_launch": True, "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                          "elapsed_s": round(elapsed, 4), "rccl": comm}), flush=True)
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(a)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        sys.exit(f"[bench] --gpus {a.gpus} but WORLD_SIZE={world}: start it as `python bench.py --gpus N` or with "
+                 f"torch.distributed.run --nproc-per-node N ... --gpus N")
+    if a.dry_launch:
+        return dry_launch(a, world, rank)
     # PIXPRO_REHEARSAL=1: all ranks share the visible GPU(s) and talk over gloo.  Only for rehearsing the N>1 control
     # flow (DDP buckets, SyncBN exchanges, shard seeds, max-over-ranks timing) on a one-GPU box; never a measurement.
     rehearsal = os.environ.get("PIXPRO_REHEARSAL") == "1"
     if rehearsal:
         local %= max(torch.cuda.device_count(), 1)
+    elif torch.cuda.device_count() < world:
+        sys.exit(f"[bench] {world} ranks but only {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1 or os.environ.get("PIXPRO_FORCE_DDP") == "1":
@@ -285,6 +384,20 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="gloo" if rehearsal else "nccl", init_method="env://")
+        # what the collective library itself saw: a sum of ones over the ranks and every rank's device
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)
+        devs = [None] * dist.get_world_size()
+        dist.all_gather_object(devs, f"{os.uname().nodename}:cuda{local}")
+        comm = {"world": dist.get_world_size(), "backend": dist.get_backend(), "allreduce_of_ones": int(ones.item()),
+                "devices": devs, "launcher": os.environ.get("PIXPRO_LAUNCHED_BY", "torch.distributed.run")}
+        if comm["world"] != a.gpus or comm["allreduce_of_ones"] != a.gpus:
+            sys.exit(f"[bench] the process group has {comm['world']} ranks (all-reduce of ones = "
+                     f"{comm['allreduce_of_ones']}), --gpus says {a.gpus}")
+        if not rehearsal and len(set(devs)) != len(devs):
+            sys.exit(f"[bench] two ranks share a GPU: {devs}")
+    else:
+        comm = None
     import main_pretrain
     from contrast import ops, util
     from contrast.lr_scheduler import get_scheduler
@@ -293,7 +406,7 @@ def main():
     args = model_args(a, world)
     # MIOpen immediate mode: this image ships no gfx950 find-db, and an exhaustive find on a fresh box
     # compiles for many minutes; the heuristic picks the prebuilt CK implicit-GEMM kernels at once
-    from contrast.miopen_tuning import use_shipped_db
+    from contrast.miopen_tuning import use_shipped_db, status as miopen_status
     tuned = use_shipped_db()      # MIOpen's own find-db for these shapes, recorded on an MI355X (contrast/miopen_tuning.py)
     torch.backends.cudnn.benchmark = bool(int(os.environ.get("PIXPRO_MIOPEN_FIND", "0")))
     note(rank, f"MIOpen: shipped find-db {'in use' if tuned else 'not used'}, find mode {torch.backends.cudnn.benchmark}")
@@ -317,6 +430,8 @@ def main():
         torch.cuda.synchronize()
         note(rank, f"warm-up step {i}: {time.perf_counter() - tw:.2f} s")
     torch.cuda.synchronize()
+    miopen_note = miopen_status()
+    note(rank, f"MIOpen: {miopen_note}")
     clock.reset()
     if world > 1:
         dist.barrier()
@@ -409,8 +524,7 @@ def main():
                                    f"p=2, transform_layer=1, LARS, fp32",
                        "batch_norm": "fused HIP SyncBN+ReLU" if a.fused_bn else "torch (Sync)BatchNorm",
                        "key_branch": "second HIP stream" if a.overlap_momentum else "same stream",
-                       "miopen": "immediate mode + find-db recorded on MI355X (pixpro-with-opticalflow_amd/miopen_db)"
-                                 if tuned else "immediate mode, library heuristics",
+                       "miopen": f"immediate mode; {miopen_note}",
                        "flow_mode": "lazy (flow + mask evaluated at the loss sample points)" if a.lazy_flow else "dense",
                        "per_gpu_batch": a.batch, "global_batch": a.batch * world,
                        "parallelism": f"dp{world}" if world > 1 else "single", "final_loss": round(final_loss, 5),
@@ -418,6 +532,8 @@ def main():
             "roofline": dict(kernel=dominant, **kernels[dominant]) if dominant else None,
             "hot_kernels": kernels,
         }
+        if comm:
+            out["rccl"] = comm
         if world == 1 and not a.no_cpu_baseline:
             note(rank, "timing the CPU oracle on a bounded sample")
             cb = cpu_baseline(a, args)

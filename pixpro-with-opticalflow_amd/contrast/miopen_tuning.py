@@ -1,24 +1,64 @@
-"""MIOpen solver selection for the encoders' convolutions.
+"""MIOpen solver selection for the encoders' convolutions (outside the hot path; kept because BASELINE's metric is the
+whole step).
 
 This image ships no gfx950 find-db, so out of the box MIOpen's immediate mode runs its naive fall-back kernels on the
 first call of every configuration (first step ~80 s) and then one heuristic choice per configuration.  The files under
 `pixpro-with-opticalflow_amd/miopen_db/` are MIOpen's own user find-db / perf-db / kernel cache, written by MIOpen
-itself during one `torch.backends.cudnn.benchmark = True` run of `bench.py` on an MI355X (462 s of tuning for the
-ResNet-50, 224^2, batch-256 configurations; tools/README in DESIGN.md 5).  Pointing MIOpen at them makes it pick the
-measured-fastest solver per configuration at once: 246 -> 228 ms per step.  Configurations that are not in the files
-behave exactly as before.  A user's own MIOPEN_USER_DB_PATH / MIOPEN_CUSTOM_CACHE_DIR is never overridden.
+itself during one `torch.backends.cudnn.benchmark = True` run of `bench.py` on an MI355X.  They are keyed to ONE MIOpen
+build string (it is part of the file names); another MIOpen build ignores them silently and falls back to its
+heuristics, which is why `status()` exists: bench.py prints it and puts it into the JSON line.
+
+The shipped files are never written to: they are copied into a per-process scratch directory and MIOpen is pointed at
+the copy (several ranks, or configurations MIOpen has not seen, would otherwise append to git-tracked files).  A user's
+own MIOPEN_USER_DB_PATH / MIOPEN_CUSTOM_CACHE_DIR is never overridden.
 """
+import atexit
 import os
+import re
+import shutil
+import tempfile
 
 DB_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "miopen_db")
+_run_dir = None
+
+
+def _shipped():
+    return sorted(f for f in os.listdir(DB_DIR) if f.endswith(".ufdb.txt")) if os.path.isdir(DB_DIR) else []
 
 
 def use_shipped_db():
-    """Call before the first convolution.  Returns True when the shipped files are in use."""
-    if os.environ.get("PIXPRO_NO_MIOPEN_DB") == "1" or not os.path.isdir(DB_DIR):
+    """Call before the first convolution.  Returns True when (a private copy of) the shipped files is in use."""
+    global _run_dir
+    if os.environ.get("PIXPRO_NO_MIOPEN_DB") == "1" or not _shipped():
         return False
-    if not any(f.endswith(".ufdb.txt") for f in os.listdir(DB_DIR)) or not os.access(DB_DIR, os.W_OK):
-        return False
-    os.environ.setdefault("MIOPEN_USER_DB_PATH", DB_DIR)
-    os.environ.setdefault("MIOPEN_CUSTOM_CACHE_DIR", DB_DIR)
-    return os.environ["MIOPEN_USER_DB_PATH"] == DB_DIR
+    if "MIOPEN_USER_DB_PATH" in os.environ or "MIOPEN_CUSTOM_CACHE_DIR" in os.environ:
+        return _run_dir is not None and os.environ.get("MIOPEN_USER_DB_PATH") == _run_dir
+    _run_dir = tempfile.mkdtemp(prefix=f"pixpro_miopen_r{os.environ.get('RANK', '0')}_")
+    for f in os.listdir(DB_DIR):
+        shutil.copy2(os.path.join(DB_DIR, f), os.path.join(_run_dir, f))
+    atexit.register(shutil.rmtree, _run_dir, ignore_errors=True)
+    os.environ["MIOPEN_USER_DB_PATH"] = _run_dir
+    os.environ["MIOPEN_CUSTOM_CACHE_DIR"] = _run_dir
+    return True
+
+
+def status():
+    """One line for the log / the bench record: do the shipped files belong to the MIOpen that is running?
+
+    Two checks.  (1) version: the shipped file name carries `<major>_<minor>_<patch>`; torch.backends.cudnn.version()
+    is MIOpen's `major*1e6 + minor*1e3 + patch`.  (2) after the first convolutions MIOpen has opened its user db under
+    its own name: a second `*.ufdb.txt` in the run directory means its build string differs from the shipped one."""
+    import torch
+    if _run_dir is None:
+        return "library heuristics in use (shipped find-db not selected)"
+    shipped = _shipped()[0]
+    m = re.search(r"\.HIP\.(\d+)_(\d+)_(\d+)_", shipped)
+    want = tuple(int(x) for x in m.groups()) if m else None
+    v = torch.backends.cudnn.version() or 0
+    have = (v // 1000000, v // 1000 % 1000, v % 1000)
+    mine = sorted(f for f in os.listdir(_run_dir) if f.endswith(".ufdb.txt"))
+    foreign = [f for f in mine if f != shipped]
+    if (want and have != want) or foreign:
+        return (f"library heuristics in use: the shipped find-db is for MIOpen build '{shipped[:-len('.ufdb.txt')]}', "
+                f"this MIOpen is {'.'.join(map(str, have))}" + (f" and opened '{foreign[0]}'" if foreign else ""))
+    return f"shipped find-db matches this MIOpen ({'.'.join(map(str, have))})"

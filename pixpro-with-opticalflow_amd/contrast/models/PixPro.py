@@ -124,9 +124,9 @@ class PixPro(BaseModel):
                 self._convert_bn(m)
 
         world = get_world_size() if is_initialized() else 1
-        per_epoch = args.num_instances * 1. / world / args.batch_size
-        self.K = int(per_epoch * args.epochs)                       # PixPro.py:294
-        self.k = int(per_epoch * (args.start_epoch - 1))            # PixPro.py:295
+        self._steps_per_epoch = args.num_instances * 1. / world / args.batch_size
+        self.K = int(self._steps_per_epoch * args.epochs)           # PixPro.py:294
+        self.k = self.steps_before_epoch(args.start_epoch)          # PixPro.py:295
 
         if self.pixpro_transform_layer == 0:
             self.value_transform = Identity()
@@ -160,9 +160,15 @@ class PixPro(BaseModel):
         for a, b in pairs:
             yield from zip(a.parameters(), b.parameters())
 
+    def steps_before_epoch(self, epoch):
+        """EMA step counter at the start of `epoch` (PixPro.py:295); also what a resume restores."""
+        return int(self._steps_per_epoch * (epoch - 1))
+
     def momentum_coefficient(self):
-        """1 - (1-m)(cos(pi k/K)+1)/2, PixPro.py:326."""
-        return 1. - (1. - self.pixpro_momentum) * (math.cos(math.pi * self.k / self.K) + 1) / 2.
+        """1 - (1-m)(cos(pi k/K)+1)/2, PixPro.py:326.  k/K is held at 1 once the schedule has run out (a loader with more
+        steps per epoch than num_instances / (world * batch) would otherwise wrap the cosine back towards m)."""
+        frac = min(self.k / self.K, 1.) if self.K > 0 else 1.
+        return 1. - (1. - self.pixpro_momentum) * (math.cos(math.pi * frac) + 1) / 2.
 
     @torch.no_grad()
     def _momentum_update_key_encoder(self):
@@ -192,8 +198,10 @@ class PixPro(BaseModel):
         overlap = self.overlap_momentum and im_1.is_cuda
         if overlap:
             # the key branch (EMA update + two no-grad passes) depends on nothing the online branch produces: it runs on a
-            # second stream, filling the CUs the small late-stage kernels leave idle and, with several ranks, the waits on the
-            # SyncBN collectives.  Collectives are still issued in host program order, identical on every rank.
+            # second stream, filling the CUs the small late-stage kernels leave idle.  Measured with one rank only.  With
+            # several ranks every SyncBN collective of the process is queued on ProcessGroupNCCL's one internal stream in
+            # host order, so the online branch's first collective waits for all of the key branch's: no overlap is to be
+            # expected there and bench.py / main_pretrain leave the flag off for world > 1 unless it is forced.
             main = torch.cuda.current_stream()
             if self._side_stream is None:
                 self._side_stream = torch.cuda.Stream(device=im_1.device)

@@ -2,7 +2,7 @@
 
 Signatures follow the reference's contrast/util.py (apply_optical_flow :175, all_concat_flow :105,
 forward_backward_consistency :253, concat_flow :301, normalize_coord :334, normalize_flow :343,
-denormalize_flow :352, calc_mask_ratio :361, AverageMeter :10, reduce_tensor :64); `upflow8` is the
+denormalize_flow :352, calc_mask_ratio :361, AverageMeter :10); `upflow8` is the
 reference's contrast/flow/utils/utils.py:87.  `calc_frame_ratio` is called by the reference's
 main_pretrain.py:230 but defined nowhere (defect D1); it is defined here with the contract its caller
 needs.  The online branch (a RAFT flow model instead of flow files, util.py:76-171,200-203) runs contrast/flow/raft.py
@@ -12,7 +12,6 @@ import argparse
 import os
 
 import torch
-import torch.distributed as dist
 
 from . import _native as nv
 
@@ -29,29 +28,6 @@ class AverageMeter(object):
         self.sum += val * n
         self.count += n
         self.avg = self.sum / self.count
-
-
-def accuracy(output, target, topk=(1,)):
-    """Top-k precision in percent for each k (reference util.py:33-47; used by the evaluation stages)."""
-    with torch.no_grad():
-        ranks = output.topk(max(topk), dim=1).indices
-        hit = ranks.eq(target.view(-1, 1))
-        return [hit[:, :k].any(dim=1).float().sum().mul_(100.0 / target.size(0)).reshape(1) for k in topk]
-
-
-def dist_collect(x):
-    """All-gather along dim 0 (reference util.py:50-61)."""
-    x = x.contiguous()
-    parts = [torch.empty_like(x) for _ in range(dist.get_world_size())]
-    dist.all_gather(parts, x)
-    return torch.cat(parts, dim=0)
-
-
-def reduce_tensor(tensor):
-    rt = tensor.clone()
-    dist.all_reduce(rt, op=dist.ReduceOp.SUM)
-    rt /= dist.get_world_size()
-    return rt
 
 
 class MyHelpFormatter(argparse.MetavarTypeHelpFormatter, argparse.ArgumentDefaultsHelpFormatter):

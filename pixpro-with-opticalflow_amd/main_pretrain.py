@@ -65,20 +65,39 @@ def save_checkpoint(args, epoch, model, optimizer, scheduler):
     copyfile(file_name, os.path.join(args.output_dir, 'current.pth'))
 
 
+def _safe_load(path):
+    """Checkpoints are untrusted pickles (a PixPro checkpoint from upstream is whatever its author saved): load them
+    with torch's restricted unpickler only.  The reference stores `opt` as an argparse.Namespace (main_pretrain.py:118),
+    which is plain data and is allow-listed; anything else non-tensor is refused by torch.load."""
+    import argparse
+    with torch.serialization.safe_globals([argparse.Namespace]):
+        return torch.load(path, map_location='cpu', weights_only=True)
+
+
 def load_checkpoint(args, model, optimizer, scheduler):
-    ckpt = torch.load(args.resume, map_location='cpu', weights_only=False)
+    ckpt = _safe_load(args.resume)
     args.start_epoch = ckpt['epoch'] + 1
     model.load_state_dict(ckpt['model'])
     optimizer.load_state_dict(ckpt['optimizer'])
-    scheduler.load_state_dict(ckpt['scheduler'])
+    sched = ckpt['scheduler']
+    if 'after_scheduler' in sched:
+        # the reference's GradualWarmupScheduler layout (contrast/lr_scheduler.py): the closed-form schedule here needs
+        # only the step count, which both layouts keep as `last_epoch`
+        sched = {'last_epoch': sched['last_epoch']}
+        scheduler.last_epoch = sched['last_epoch']
+        for g, lr in zip(optimizer.param_groups, [base * f(scheduler.last_epoch)
+                                                  for base, f in zip(scheduler.base_lrs, scheduler.lr_lambdas)]):
+            g['lr'] = lr
+        scheduler._last_lr = [g['lr'] for g in optimizer.param_groups]
+    else:
+        scheduler.load_state_dict(sched)
     inner = model.module if hasattr(model, "module") else model
-    per_epoch = inner.K / max(args.epochs, 1)
-    inner.k = int(per_epoch * (args.start_epoch - 1))          # PixPro.py:295
+    inner.k = inner.steps_before_epoch(args.start_epoch)        # PixPro.py:295, the constructor's own expression
     log(f"=> resumed '{args.resume}' (epoch {ckpt['epoch']})")
 
 
 def load_pretrained(model, path):
-    ckpt = torch.load(path, map_location='cpu', weights_only=False)
+    ckpt = _safe_load(path)
     sd = model.state_dict()
     sd.update(ckpt['model'])
     model.load_state_dict(sd)
@@ -159,6 +178,10 @@ def main(args, device):
     if not args.synthetic:
         raise NotImplementedError("the BDD100k video loader is outside this build; run with --synthetic")
     size = args.image_size if isinstance(args.image_size, int) else args.image_size[0]
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    # the EMA schedule (PixPro.py:294) counts num_instances / (world * batch) steps per epoch and the LR schedule counts
+    # len(loader): with the synthetic loader the epoch length is --steps-per-epoch, so make the two agree
+    args.num_instances = args.steps_per_epoch * args.batch_size * world
     loader = SyntheticLoader(args.steps_per_epoch, args.batch_size, image_size=size, n_frames=max(args.n_frames, 2),
                              frame_hw=tuple(args.frame_size), device=device, flow_up=args.flow_up,
                              with_flow=args.use_flow, with_frames=args.use_flow and not args.use_flow_file, channels_last=getattr(args, "channels_last", False), seed=1234 + (dist.get_rank() if dist.is_initialized() else 0))
@@ -175,6 +198,9 @@ def main(args, device):
         load_checkpoint(args, model, optimizer, scheduler)
     for epoch in range(args.start_epoch, args.epochs + 1):
         train(epoch, loader, model, optimizer, scheduler, args, flow_model)
+        if epoch == args.start_epoch:
+            from contrast.miopen_tuning import status
+            log(f"MIOpen: {status()}")
         rank0 = not dist.is_initialized() or dist.get_rank() == 0
         if rank0 and (epoch % args.save_freq == 0 or epoch == args.epochs):
             save_checkpoint(args, epoch, model, optimizer, scheduler)

@@ -144,9 +144,12 @@ def test_checkpoint_resume_roundtrip(dev, tmp_path):
     data = make_batch(4, image_size=64, n_frames=2, frame_hw=(96, 128), device=dev)
     args, model, opt, sched = build()
     model.train()
-    for _ in range(2):
+    # one whole epoch of the EMA schedule: num_instances / batch = 4 steps (PixPro.py:294-295 counts k from the epoch)
+    for _ in range(4):
         main_pretrain.train_step(model, opt, sched, data, args)
     main_pretrain.save_checkpoint(args, 1, model, opt, sched)
+    k_at_save, m_at_save, lr_at_save = model.k, model.momentum_coefficient(), opt.param_groups[0]["lr"]
+    assert k_at_save == 4
     loss_a, _, _ = main_pretrain.train_step(model, opt, sched, data, args)
     w_a = model.value_transform.weight.detach().clone()
 
@@ -154,13 +157,16 @@ def test_checkpoint_resume_roundtrip(dev, tmp_path):
     args2.resume = str(tmp_path / "current.pth")
     main_pretrain.load_checkpoint(args2, model2, opt2, sched2)
     assert args2.start_epoch == 2
+    # the counter load_checkpoint restores is the one the interrupted run had: same momentum for the next EMA update
+    assert model2.k == k_at_save and model2.momentum_coefficient() == m_at_save
+    assert sched2.last_epoch == 4 and lr_at_save == pytest.approx(opt2.param_groups[0]["lr"], rel=1e-12)
     model2.train()
-    model2.k = model.k - 1                      # the EMA counter one step before the saved step's successor
     loss_b, _, _ = main_pretrain.train_step(model2, opt2, sched2, data, args2)
     # MIOpen's weight-gradient kernels and the LARS norm reduction accumulate with float atomics: equal up to
     # re-association, not bit for bit
     assert abs(loss_a.item() - loss_b.item()) <= 1e-5 * max(1.0, abs(loss_a.item()))
     assert torch.allclose(w_a, model2.value_transform.weight.detach(), rtol=1e-4, atol=1e-6)
+    assert model2.k == model.k == 5
 
 
 def test_public_featprop_and_instance_branch(dev):

@@ -161,13 +161,6 @@ def test_fused_bn_conversion_keeps_names_and_has_no_cpu_route():
     assert torch.equal(bn_act(bn, x, relu=True, residual=r), torch.relu(bn(x) + r))
 
 
-def test_accuracy_helper():
-    from contrast import util
-    out = torch.tensor([[0.1, 0.7, 0.2], [0.8, 0.1, 0.1], [0.2, 0.3, 0.5]])
-    top1, top2 = util.accuracy(out, torch.tensor([1, 0, 1]), topk=(1, 2))
-    assert abs(top1.item() - 200.0 / 3) < 1e-4 and top2.item() == 100.0
-
-
 def test_product_and_tools_never_touch_the_oracle():
     """oracle/ is test infrastructure: nothing under the package or tools/ may import it, and the product must fail
     loudly without the HIP library instead of falling back."""
@@ -188,3 +181,122 @@ def test_product_and_tools_never_touch_the_oracle():
             _native.load()
     finally:
         _native._lib, _native.LIB_PATH = saved
+
+
+def _tiny_pixpro(**over):
+    from contrast import resnet
+    from contrast.models import PixPro
+    a = dict(pixpro_p=2.0, pixpro_momentum=0.99, pixpro_pos_ratio=0.7, pixpro_clamp_value=0.0, pixpro_transform_layer=1,
+             pixpro_ins_loss_weight=0.0, output_dir="/tmp", num_instances=64, batch_size=4, epochs=3, start_epoch=1,
+             feature_dim=256, head_type="early_return", sync_bn=False)
+    a.update(over)
+    return PixPro(resnet.resnet18, types.SimpleNamespace(**a))
+
+
+def test_momentum_schedule_is_clamped_and_resume_counter_matches_constructor():
+    """k must not wrap the cosine once it passes K; a resume computes k with the constructor's expression."""
+    m = _tiny_pixpro()
+    assert m.K == 48 and m.k == 0 and m.momentum_coefficient() == pytest.approx(0.99)
+    m.k = m.K
+    assert m.momentum_coefficient() == pytest.approx(1.0)
+    m.k = 2 * m.K          # a loader with more steps than num_instances / batch: stays at 1, the cosine does not come back
+    assert m.momentum_coefficient() == pytest.approx(1.0)
+    # PixPro.py:295 with a fractional steps-per-epoch: int(10.5 * 2) = 21, not 2 * int(10.5)
+    m2 = _tiny_pixpro(num_instances=42, start_epoch=3)
+    assert m2.k == 21 and m2.steps_before_epoch(3) == 21 and m2.K == 31
+
+
+def test_checkpoints_are_loaded_with_the_restricted_unpickler(tmp_path):
+    """a checkpoint is an untrusted pickle.  Tensors + plain containers + the reference's
+    argparse.Namespace load; anything else is refused instead of executed."""
+    import argparse
+    import main_pretrain
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, ("echo pwned > %s" % (tmp_path / "pwned"),))
+
+    good = tmp_path / "good.pth"
+    torch.save({"model": {"w": torch.ones(2)}, "epoch": 3, "opt": argparse.Namespace(lr=0.1, arch="resnet50")}, good)
+    ck = main_pretrain._safe_load(str(good))
+    assert ck["epoch"] == 3 and ck["opt"].arch == "resnet50" and torch.equal(ck["model"]["w"], torch.ones(2))
+    bad = tmp_path / "bad.pth"
+    torch.save({"model": {"w": torch.ones(2)}, "epoch": 3, "opt": Evil()}, bad)
+    with pytest.raises(Exception, match="(?i)unsupported|weights_only|not an allowed"):
+        main_pretrain._safe_load(str(bad))
+    assert not (tmp_path / "pwned").exists()
+    model = torch.nn.Linear(2, 2)
+    with pytest.raises(Exception):
+        main_pretrain.load_pretrained(model, str(bad))
+
+
+def test_resume_accepts_the_reference_scheduler_layout(tmp_path):
+    """the reference saves a GradualWarmupScheduler state dict (keys multiplier, total_epoch, after_scheduler,
+    last_epoch ...).  Only the step count matters for the closed-form schedule here."""
+    import main_pretrain
+    from contrast import option
+    from contrast.lr_scheduler import get_scheduler
+    args = option.parse_option(argv=["--model", "PixPro", "--arch", "resnet18", "--synthetic", "--optimizer", "sgd",
+                                     "--base-lr", "0.1", "--batch-size", "4", "--epochs", "4", "--warmup-epoch", "1"])
+
+    class M(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.lin = torch.nn.Linear(2, 2)
+            self.k = -1
+
+        def steps_before_epoch(self, epoch):
+            return 10 * (epoch - 1)
+
+    def fresh():
+        m = M()
+        o = torch.optim.SGD(m.parameters(), lr=0.5, momentum=0.9)
+        return m, o, get_scheduler(o, 10, args)
+
+    m, o, s = fresh()
+    for _ in range(17):
+        o.step()
+        s.step()
+    lr17 = o.param_groups[0]["lr"]
+    ref_sched = {"multiplier": 100, "total_epoch": 10, "after_scheduler": {"T_max": 30, "eta_min": 1e-6, "last_epoch": 7},
+                 "finished": True, "last_epoch": 17, "base_lrs": [0.5], "_step_count": 18}
+    path = tmp_path / "ref.pth"
+    torch.save({"model": m.state_dict(), "optimizer": o.state_dict(), "scheduler": ref_sched, "epoch": 2}, path)
+    m2, o2, s2 = fresh()
+    args.resume = str(path)
+    main_pretrain.load_checkpoint(args, m2, o2, s2)
+    assert args.start_epoch == 3 and m2.k == 20 and s2.last_epoch == 17
+    assert o2.param_groups[0]["lr"] == pytest.approx(lr17, rel=1e-12)
+    o2.step(); s2.step(); o.step(); s.step()
+    assert o2.param_groups[0]["lr"] == pytest.approx(o.param_groups[0]["lr"], rel=1e-12)
+    # our own layout still round-trips
+    torch.save({"model": m.state_dict(), "optimizer": o.state_dict(), "scheduler": s.state_dict(), "epoch": 2}, path)
+    m3, o3, s3 = fresh()
+    main_pretrain.load_checkpoint(args, m3, o3, s3)
+    assert s3.last_epoch == 18 and o3.param_groups[0]["lr"] == pytest.approx(o.param_groups[0]["lr"], rel=1e-12)
+
+
+def test_shipped_miopen_db_is_copied_not_written(monkeypatch):
+    """MIOpen must never append to the git-tracked files; each process gets a private copy."""
+    from contrast import miopen_tuning as mt
+    monkeypatch.delenv("MIOPEN_USER_DB_PATH", raising=False)
+    monkeypatch.delenv("MIOPEN_CUSTOM_CACHE_DIR", raising=False)
+    monkeypatch.setattr(mt, "_run_dir", None)
+    before = {f: os.path.getmtime(os.path.join(mt.DB_DIR, f)) for f in os.listdir(mt.DB_DIR)}
+    assert mt.use_shipped_db() is True
+    run_dir = os.environ["MIOPEN_USER_DB_PATH"]
+    monkeypatch.setenv("MIOPEN_USER_DB_PATH", run_dir)          # so monkeypatch restores the environment afterwards
+    monkeypatch.setenv("MIOPEN_CUSTOM_CACHE_DIR", run_dir)
+    assert run_dir != mt.DB_DIR and os.environ["MIOPEN_CUSTOM_CACHE_DIR"] == run_dir
+    assert sorted(os.listdir(run_dir)) == sorted(before)
+    assert mt.use_shipped_db() is True                          # idempotent
+    st = mt.status()
+    assert "find-db" in st
+    # a MIOpen with another build string opens its own file next to the copy: reported, not silent
+    open(os.path.join(run_dir, "gfx950100.HIP.9_9_9_other.ufdb.txt"), "w").close()
+    assert mt.status().startswith("library heuristics in use")
+    assert {f: os.path.getmtime(os.path.join(mt.DB_DIR, f)) for f in os.listdir(mt.DB_DIR)} == before
+    # the user's own choice wins
+    monkeypatch.setattr(mt, "_run_dir", None)
+    monkeypatch.setenv("MIOPEN_USER_DB_PATH", "/somewhere/else")
+    assert mt.use_shipped_db() is False and os.environ["MIOPEN_USER_DB_PATH"] == "/somewhere/else"
