@@ -31,25 +31,46 @@ HBM_PEAK = 8.0e12        # B/s, MI355X_MICROARCH.md
 MFMA_F32_PEAK = 157.3e12  # FLOP/s, MI355X_MICROARCH.md
 
 
+def _pmc_file():
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    return os.path.relpath(found[-1], ROOT) if found else None
+
+
+PMC_FILE = _pmc_file()      # the latest round's kept summary
+
+
 def pmc_traffic(kernel, a):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.json: FETCH_SIZE and
-    WRITE_SIZE collected separately, gfx950 corrections applied as the file's note says).  Only valid for the
-    configuration it was collected on; traffic scales linearly with the batch."""
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in separate
+    passes by tools/pmc_traffic.sh, gfx950 corrections applied as the file's note says).  It is a kept summary, not a
+    counter read during this run (`traffic_source` on the JSON line says so); only valid for the configuration it was
+    collected on, scaled linearly with the batch.  Returns (bytes | None, source | None)."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
+        with open(os.path.join(ROOT, PMC_FILE or "")) as fh:
             t = json.load(fh)
     except OSError:
-        return None
+        return None, None
     if a.image_size != 224 or a.n_frames != 2 or kernel not in t:
-        return None
-    return int(t[kernel]["hbm_bytes_per_image"] * a.batch)
+        return None, None
+    return int(t[kernel]["hbm_bytes_per_image"] * a.batch), f"{PMC_FILE}, collected at N={t.get('N', 256)}, scaled to N={a.batch}"
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=50, help="timed steps (SURVEY 8d protocol: >= 50)")
+    ap.add_argument("--warmup", type=int, default=20, help="untimed warm-up steps (SURVEY 8d protocol: >= 20)")
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (BASELINE configs[1]: 256 on 1 GPU)")
     ap.add_argument("--image-size", type=int, default=224)
     ap.add_argument("--n-frames", type=int, default=2)
@@ -212,7 +233,7 @@ def cpu_baseline(a, args):
         reps += 1
     t_ppm = t_ppm / reps / N
     return {"value": round(1.0 / (t_flow + t_ppm), 2), "unit": "images/s (hot path only: flow prep + PPM/loss fwd+bwd)",
-            "cores": threads, "kind": "port",
+            "cores": threads, "cpu_model": cpu_model(), "kind": "port",
             "sample": f"oracle/pixpro_oracle.py (ATen samplers), torch-CPU fp32, {threads} threads: flow prep nframe={a.n_frames} "
                       f"720x1280 on {nf} images ({t_flow * 1e3:.1f} ms/img) + PPM/loss fwd+bwd on {N} images x{reps} "
                       f"({t_ppm * 1e3:.3f} ms/img); encoders excluded",
@@ -450,15 +471,34 @@ def main():
         elapsed = t.item()
     final_loss = loss.item()
     ms = clock.mean_ms()
-    bn = None
-    if a.fused_bn and rank == 0 and world == 1:
-        audit = BnAudit()
-        audit.install(_native)
+    note(rank, f"timed {a.steps} steps in {elapsed:.2f} s; hot kernels (ms): {ms}")
+    # Two extra, untimed steps (rank 0, one rank only) for figures the timed region cannot give cleanly:
+    #  (1) everything on ONE stream: with the key branch on its second stream an event pair spans shared-GPU time, so the
+    #      per-call clocks of the BN kernels and of the EMA launch are only meaningful here (reproduces the rocprof sums);
+    #  (2) the sparse ("lazy") flow variant of the loss kernel, reported separately from the dense one.
+    bn = ms_single = ms_lazy = None
+    if rank == 0 and world == 1:
+        inner = model.module if hasattr(model, "module") else model
+        saved_overlap, inner.overlap_momentum = inner.overlap_momentum, False
+        clock.reset()
+        audit = BnAudit() if a.fused_bn else None
+        if audit:
+            audit.install(_native)
         main_pretrain.train_step(model, optimizer, scheduler, next(iter(loader)), args)
         torch.cuda.synchronize()
-        audit.remove()
-        bn = audit.summary()
-    note(rank, f"timed {a.steps} steps in {elapsed:.2f} s; hot kernels (ms): {ms}")
+        if audit:
+            audit.remove()
+            bn = audit.summary()
+        ms_single = clock.mean_ms()
+        if not a.lazy_flow:
+            clock.reset()
+            args.lazy_flow = True
+            main_pretrain.train_step(model, optimizer, scheduler, next(iter(loader)), args)
+            torch.cuda.synchronize()
+            args.lazy_flow = False
+            ms_lazy = clock.mean_ms()
+        inner.overlap_momentum = saved_overlap
+        note(rank, f"single-stream audit step (ms): {ms_single}; lazy-flow step (ms): {ms_lazy}")
 
     if rank == 0:
         P = (a.image_size // 32) ** 2
@@ -473,7 +513,8 @@ def main():
             t = ms["flow_prepare"] * 1e-3
             kernels["flow_prepare"] = {"bound": "hbm", "achieved": round(b_flow * a.batch / t / 1e9, 1), "peak": HBM_PEAK / 1e9,
                                        "unit": "GB/s", "frac": round(b_flow * a.batch / t / HBM_PEAK, 4),
-                                       "traffic": pmc_traffic("flow_prepare", a),
+                                       "traffic": pmc_traffic("flow_prepare", a)[0],
+                                       "traffic_source": pmc_traffic("flow_prepare", a)[1],
                                        "ms_per_launch": round(ms["flow_prepare"], 4),
                                        "algorithmic_bytes_per_launch": int(b_flow * a.batch),
                                        "compulsory_bytes_per_launch": int((F1 * A / 16 + 4.5 * A) * a.batch),
@@ -486,7 +527,8 @@ def main():
             kernels["ppm_loss"] = {"bound": "mfma", "achieved": round(f_ppm * a.batch / t / 1e12, 3),
                                    "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
                                    "frac": round(f_ppm * a.batch / t / MFMA_F32_PEAK, 4),
-                                   "traffic": pmc_traffic("ppm_loss", a),
+                                   "traffic": pmc_traffic("ppm_loss", a)[0],
+                                   "traffic_source": pmc_traffic("ppm_loss", a)[1],
                                    "ms_per_launch": round(ms["ppm_loss"], 4),
                                    "algorithmic_flops_per_launch": int(f_ppm * a.batch),
                                    "hbm_frac": round(b_ppm * a.batch / t / HBM_PEAK, 4)}
@@ -496,22 +538,39 @@ def main():
                 kernels[extra] = {"bound": "hbm", "achieved": round(nbytes / t / 1e9, 1), "peak": HBM_PEAK / 1e9,
                                   "unit": "GB/s", "frac": round(nbytes / t / HBM_PEAK, 4), "traffic": None,
                                   "ms_per_launch": round(ms[extra], 4), "algorithmic_bytes_per_launch": nbytes}
-                if extra == "ema_update" and a.overlap_momentum:
-                    kernels[extra]["note"] = ("runs on the second stream next to the online branch's kernels: the event "
-                                              "pair spans shared-GPU time (0.125 ms = 3.2 TB/s alone, --no-overlap-momentum)")
+                if extra == "ema_update" and a.overlap_momentum and ms_single and extra in ms_single:
+                    # in the timed steps this launch shares the GPU with the online branch (second stream): the figure
+                    # that prices the kernel is the single-stream audit step's
+                    t1 = ms_single[extra] * 1e-3
+                    kernels[extra].update({"achieved": round(nbytes / t1 / 1e9, 1), "frac": round(nbytes / t1 / HBM_PEAK, 4),
+                                           "ms_per_launch": round(ms_single[extra], 4),
+                                           "ms_per_launch_overlapped": round(ms[extra], 4),
+                                           "note": "achieved/frac from the single-stream audit step; in the timed steps the "
+                                                   "launch runs on the second stream next to the online branch"})
+        if ms_lazy and "ppm_loss" in ms_lazy:
+            t = ms_lazy["ppm_loss"] * 1e-3
+            kernels["ppm_loss_lazy"] = {"bound": "mfma", "achieved": round(f_ppm * a.batch / t / 1e12, 3),
+                                        "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
+                                        "frac": round(f_ppm * a.batch / t / MFMA_F32_PEAK, 4), "traffic": None,
+                                        "ms_per_launch": round(ms_lazy["ppm_loss"], 4),
+                                        "algorithmic_flops_per_launch": int(f_ppm * a.batch),
+                                        "note": "sparse variant (--lazy-flow), one extra untimed step: no flow_prepare launch, "
+                                                "flow chain + consistency mask evaluated at the loss sample points inside "
+                                                "this launch; never mixed with the dense figures"}
         if bn:
             n_l = sum(v[0] for v in bn.values())
             t_ms = sum(v[1] for v in bn.values())
             nb = sum(v[2] for v in bn.values())
             kernels["batch_norm"] = {"bound": "hbm", "achieved": round(nb / (t_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK / 1e9,
                                      "unit": "GB/s", "frac": round(nb / (t_ms * 1e-3) / HBM_PEAK, 4),
-                                     "traffic": pmc_traffic("batch_norm", a) if a.arch == "resnet50" else None,
+                                     "traffic": pmc_traffic("batch_norm", a)[0] if a.arch == "resnet50" else None,
+                                     "traffic_source": pmc_traffic("batch_norm", a)[1] if a.arch == "resnet50" else None,
                                      "ms_per_step": round(t_ms, 3), "launch_pairs_per_step": n_l,
                                      "algorithmic_bytes_per_step": int(nb),
                                      "by_call": {k: {"n": v[0], "ms": round(v[1], 3),
                                                      "GB/s": round(v[2] / (v[1] * 1e-3) / 1e9, 1)} for k, v in bn.items()},
-                                     "note": "fused (Sync)BatchNorm + ReLU + residual add, one audited step; bytes = tensor "
-                                             "passes x rows x C x 4 (DESIGN.md 4.7)"}
+                                     "note": "fused (Sync)BatchNorm + ReLU + residual add, one audited step with both branches "
+                                             "on one stream; bytes = tensor passes x rows x C x 4 (DESIGN.md 4.7)"}
         cand = [k for k in ("flow_prepare", "ppm_loss") if k in kernels]
         dominant = max(cand, key=lambda k: kernels[k]["ms_per_launch"]) if cand else None
         out = {

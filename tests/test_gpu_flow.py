@@ -119,3 +119,28 @@ def test_flow_properties_full_size(dev):
     assert torch.equal(m[0].cpu(), inside)
     one = torch.randn(1, 2, 2, 64, 64, device=dev)
     assert torch.equal(util.concat_flow(one), one[0])
+
+
+@pytest.mark.parametrize("nfr,N", [(6, 4), (2, 5)])
+def test_apply_optical_flow_bdd_size_batch_vs_oracle(dev, nfr, N):
+    """the dense pipeline at the production frame size (720x1280) with a real batch (sample index in
+    the grid) against the oracle bit for bit - nframe=6 is the reference's production recipe
+    (tools/pretrain_bdd100k_job_2000ep_nframe6_gpu16.sh:26-51)."""
+    from contrast import util
+    from oracle import pixpro_oracle as O
+    from recipes import smooth_flow
+    gen = torch.Generator().manual_seed(40 + nfr)
+    hw = (90, 160)
+    fw = smooth_flow((N, nfr - 1, 2, *hw), 0.5, gen)
+    fw[1] *= 6.0                                  # one sample with large displacements (taps beyond the LDS windows)
+    bw = -fw.flip(1) + smooth_flow((N, nfr - 1, 2, *hw), 0.05, gen)
+    size = torch.tensor([720, 1280])
+    (f, _, mf), (b, _, mb) = util.apply_optical_flow(_data(fw, bw, size, nfr, dev), None, _args(True))
+    with O.aten_samplers():                       # the ATen kernels the reference calls; bit-identical to the restatement
+        (fo, _, mfo), (bo, _, mbo) = O.apply_optical_flow_file(fw, bw, size, True, 0.01, 0.5)
+    assert torch.equal(f.cpu(), fo) and torch.equal(b.cpu(), bo)
+    assert torch.equal(mf.cpu(), mfo) and torch.equal(mb.cpu(), mbo)
+    for n in range(N):
+        assert 0 < mfo[n].float().mean() < 1
+    r = util.calc_mask_ratio(mf).cpu()
+    assert torch.allclose(r, (~mfo).float().mean((-1, -2)), atol=1e-6, rtol=0)

@@ -343,3 +343,30 @@ def test_regression_loss_module_function_with_lazy_flow(dev):
         out.append((loss.item(), pn.clone(), qq.grad.clone()))
     assert out[0][0] == out[1][0] and torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][2], out[1][2])
     assert out[0][1].sum() > 0
+
+
+def _full_size_problem(N, C, H, W, seed):
+    """BASELINE-sized case: 720x1280 frame, composed flow at 1/8 resolution (90x160, the ratio branch of
+    add_optical_flow), random mask with 20 % invalid pixels, overlapping random crops."""
+    return _random_problem(None, N, C, H, W, 720, 1280, seed=seed, eighth=True, sigma=1.5)
+
+
+@pytest.mark.parametrize("shape,generic", [
+    ((64, 256, 14, 14), True),      # BASELINE config 5 per-GPU size on the staged path (grid.z = 2N, blockIdx.x / N indexing)
+    ((256, 256, 7, 7), False),      # BASELINE config 2 size on the single-launch kernel, against the oracle (not the staged path)
+    ((128, 256, 7, 7), False),      # config 3 per-GPU size
+    ((64, 256, 7, 7), True),        # config 4 per-GPU size on the staged path
+])
+def test_full_size_vs_oracle(dev, shape, generic):
+    """batch-size-dependent indexing at the BASELINE sizes checked against the CPU oracle, not
+    against another HIP path.  pos_num exact, |loss| 1e-5, pred 2e-6, grads 1e-4 of max-abs."""
+    N, C, H, W = shape
+    P = _full_size_problem(N, C, H, W, seed=N + H)
+    lo, pno, go, (p1, p2) = _run_oracle(P)
+    out, gh = _run_hip(dev, P, generic=generic, want_pred=True)
+    assert torch.equal(out[1].cpu(), pno)
+    assert pno.sum() > 0 and (pno > 0).sum() >= N // 2        # the overlapping half of the crops has positives
+    assert abs(out[0].item() - lo) <= 1e-5 * max(1.0, abs(lo))
+    assert (out[4][0].cpu() - p1).abs().max() <= 2e-6 and (out[4][1].cpu() - p2).abs().max() <= 2e-6
+    for a, b in zip(gh, go):
+        close(a, b)
