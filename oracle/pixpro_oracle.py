@@ -278,11 +278,23 @@ def ppm_loss_grad_analytic(x, v, k, M, p, clamp, upstream=1.0):
 # --------------------------------------------------------------------------------------
 # K5  upflow8                             contrast/flow/utils/utils.py:87-89
 # --------------------------------------------------------------------------------------
+UP8_SMALL_OUTPUT = 128   # ATen: (output_H + output_W) <= 128 selects the other CPU kernel (see upflow8)
+
+
 def upflow8(flow):
     """8 * F.interpolate(flow, size=(8h,8w), mode='bilinear', align_corners=True).
-    ATen CPU order (x86 build of torch 2.10, verified bit-for-bit): src = dst*((in-1)/(out-1));
-    i0=int(src); l1=src-i0; l0=1-l1; weights w_yx = l_y*l_x rounded to fp32;
-    out = fma(d, w11, fma(c, w10, fma(a, w00, b*w01)))  with a,b = row y0 (x0,x1), c,d = row y1."""
+
+    ATen's CPU bilinear up-sampling is TWO kernels with different operation orders, chosen by the output size
+    (`_use_vectorized_kernel_cond_2d`: output_H + output_W <= 128 -> `cpu_upsample_linear_channels_last`, else
+    `upsample_generic_Nd_kernel_impl`); both verified bit for bit against torch 2.10 (x86, FMA build) over h, w in
+    2..90 / 2..160 (tests/test_oracle_golden.py::test_aten_samplers_agree*).  Common part: src = dst*((in-1)/(out-1));
+    i0 = int(src); l1 = src-i0; l0 = 1-l1.  With a,b = row y0 (x0,x1) and c,d = row y1:
+      small outputs (8h+8w <= 128): weights w_yx = l_y*l_x rounded to fp32,
+          out = fma(d, w11, fma(c, w10, fma(a, w00, b*w01)))
+      larger outputs (every production size, e.g. 720x1280): separable, x first,
+          t0 = fma(a, lx0, b*lx1);  t1 = fma(c, lx0, d*lx1);  out = fma(t0, ly0, t1*ly1)
+    Round 1 restated only the first form (all its goldens were <= 48x64); the second was found in round 2 by the
+    720x1280 test against the ATen kernels and is pinned by the goldens upflow8_big / applyflow_*big."""
     M, C, h, w = flow.shape
     Ho, Wo = 8 * h, 8 * w
     if _ATEN_SAMPLERS:
@@ -304,10 +316,15 @@ def upflow8(flow):
     d = flow[:, :, y1][:, :, :, x1]
     ly0, ly1 = ly0.view(1, 1, -1, 1), ly1.view(1, 1, -1, 1)
     lx0, lx1 = lx0.view(1, 1, 1, -1), lx1.view(1, 1, 1, -1)
-    acc = b * (ly0 * lx1)
-    acc = _fma(a, ly0 * lx0, acc)
-    acc = _fma(c, ly1 * lx0, acc)
-    acc = _fma(d, ly1 * lx1, acc)
+    if Ho + Wo <= UP8_SMALL_OUTPUT:
+        acc = b * (ly0 * lx1)
+        acc = _fma(a, ly0 * lx0, acc)
+        acc = _fma(c, ly1 * lx0, acc)
+        acc = _fma(d, ly1 * lx1, acc)
+    else:
+        t0 = _fma(a, lx0, b * lx1)
+        t1 = _fma(c, lx0, d * lx1)
+        acc = _fma(t0, ly0, t1 * ly1)
     return 8 * acc
 
 

@@ -124,8 +124,16 @@ __device__ __forceinline__ Up8Axis up8_axis(int dst, int n_in, float scale) {
 __device__ __forceinline__ float up8_scale(int n_in) {
   return n_in > 1 ? (float)(n_in - 1) / (float)(8 * n_in - 1) : 0.f;
 }
+// ATen's CPU bilinear up-sampling is two kernels with different operation orders (oracle.upflow8): outputs with
+// out_H + out_W <= 128 take the product-weight form (cpu_upsample_linear_channels_last), everything larger - every
+// production size - the separable form (upsample_generic_Nd_kernel_impl).  a,b = row y0 (x0,x1); c,d = row y1.
+__host__ __device__ inline bool up8_separable(int h, int w) { return 8 * h + 8 * w > 128; }
+// separable form, shared pieces: the x pass of one source row and the y pass
+__device__ __forceinline__ float up8_row(float l, float r, float lx0, float lx1) { return __builtin_fmaf(l, lx0, r * lx1); }
+__device__ __forceinline__ float up8_col(float t0, float t1, float ly0, float ly1) { return __builtin_fmaf(t0, ly0, t1 * ly1); }
 __device__ __forceinline__ float up8_combine(float a, float b, float c, float d, const Up8Axis& ay,
-                                             const Up8Axis& ax) {
+                                             const Up8Axis& ax, bool sep) {
+  if (sep) return 8.f * up8_col(up8_row(a, b, ax.l0, ax.l1), up8_row(c, d, ax.l0, ax.l1), ay.l0, ay.l1);
   float acc = b * (ay.l0 * ax.l1);
   acc = __builtin_fmaf(a, ay.l0 * ax.l0, acc);
   acc = __builtin_fmaf(c, ay.l1 * ax.l0, acc);
@@ -137,11 +145,12 @@ struct FetchUp8 {
   const float* __restrict__ ly;   // low-res channel 1
   int h, w;
   float sy, sx;
+  bool sep;
   __device__ __forceinline__ void operator()(int y, int x, float& vx, float& vy) const {
     const Up8Axis ay = up8_axis(y, h, sy), ax = up8_axis(x, w, sx);
     const int o00 = ay.i0 * w + ax.i0, o01 = ay.i0 * w + ax.i1, o10 = ay.i1 * w + ax.i0, o11 = ay.i1 * w + ax.i1;
-    vx = up8_combine(lx[o00], lx[o01], lx[o10], lx[o11], ay, ax);
-    vy = up8_combine(ly[o00], ly[o01], ly[o10], ly[o11], ay, ax);
+    vx = up8_combine(lx[o00], lx[o01], lx[o10], lx[o11], ay, ax, sep);
+    vy = up8_combine(ly[o00], ly[o01], ly[o10], ly[o11], ay, ax, sep);
   }
 };
 
@@ -276,7 +285,7 @@ struct Up8Source {     // lo [N,F1,2,h,w] (loader layout), up-sampled lazily
   int F1, h, w;
   __device__ __forceinline__ FetchUp8 at(int t, int n) const {
     const float* p = lo + ((size_t)n * F1 + t) * 2 * h * w;
-    return FetchUp8{p, p + (size_t)h * w, h, w, up8_scale(h), up8_scale(w)};
+    return FetchUp8{p, p + (size_t)h * w, h, w, up8_scale(h), up8_scale(w), up8_separable(h, w)};
   }
 };
 

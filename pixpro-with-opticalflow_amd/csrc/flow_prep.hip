@@ -6,6 +6,9 @@
 // (add_optical_flow).  Arithmetic order follows oracle/pixpro_oracle.py (bit-exact targets).
 #include "common.h"
 
+#include <stdlib.h>
+#include <string.h>
+
 namespace pixpro {
 namespace {
 
@@ -22,7 +25,7 @@ __global__ void k_upflow8(const float* __restrict__ in, float* __restrict__ out,
   const float* p = in + pl * h * w;
   const Up8Axis ay = up8_axis(y, h, up8_scale(h)), ax = up8_axis(x, w, up8_scale(w));
   out[idx] = up8_combine(p[ay.i0 * w + ax.i0], p[ay.i0 * w + ax.i1], p[ay.i1 * w + ax.i0], p[ay.i1 * w + ax.i1],
-                         ay, ax);
+                         ay, ax, up8_separable(h, w));
 }
 
 // ---- K6: concat_flow ------------------------------------------------------------------
@@ -143,15 +146,22 @@ __global__ void k_prepare_single(Source sf, Source sb, float* __restrict__ flow_
   }
 }
 
-// ---- production form of the above: flow_up, F-1 == 1 ----------------------------------------
-// Same arithmetic, restructured for instruction count (the generic kernel is VALU-bound):
-//   * 2-D tiles of 256 x 4 pixels, 4 consecutive pixels per thread -> no integer division for
-//     indexing, 16-B flow stores and 4-B mask stores;
-//   * divisions by the per-launch constants (Wf-1), (Hf-1) as q0 = a*r, q = fma(fma(-q0,b,a), r, q0)
-//     with r = RN(1/b): the correctly rounded quotient (Markstein), 3 instructions instead of ~10;
-//   * a pixel whose displaced position leaves the frame is invalid whatever the cycle error, so its
-//     taps are skipped; inside the frame all four taps are in range and share two x- and two y-axes
-//     of the lazy x8 up-sampling.
+// =====================================================================================================
+// Production kernels (flow_up, output sizes on ATen's separable up-sampling path: every real frame size).
+//
+// Round 1 re-derived the x8 up-sampling of the OPPOSITE direction at each of the 2 x 4 consistency taps of every pixel
+// (~350 VALU instructions and 36 ds_read_b128 per pixel).  Here every block first stages, once, what its taps will
+// need - the up-sampled and already NORMALISED (2f/(Wf-1), 2f/(Hf-1)) flows of both directions over its tile plus a
+// halo - in LDS, and a tap becomes one 8-byte LDS read.  The staging exploits that the reference's up-sampling is
+// separable (common.h: t = fma(l, lx0, r*lx1) along x per source row, then fma(t0, ly0, t1*ly1) along y): a thread owns
+// one column of the region, keeps the two x-interpolated source rows in registers and walks down its rows, so a
+// staged pixel costs one fma+mul per channel plus the exact normalising division.  The un-normalised flows of the tile
+// (the API's dense outputs) are stored to HBM from the same loop.  Taps that leave the staged region (displacements
+// beyond the halo) take a slow, generic path with identical arithmetic (fbc_pixel over FetchUp8).
+//
+// Exact division by the per-launch constants (Wf-1), (Hf-1): q0 = a*r, q = fma(fma(-q0,b,a), r, q0) with r = RN(1/b)
+// is the correctly rounded quotient (Markstein), 3 instructions instead of ~10.
+// =====================================================================================================
 struct DivC {
   float b, rb;
 };
@@ -170,24 +180,8 @@ struct Up8Geom {
   float alpha1, a2;
 };
 
-// Block-local LDS window over the four low-res channels {fwd.x, fwd.y, bwd.x, bwd.y}, one float4 per
-// low-res cell, replicate-padded (index clamping reproduces upflow8's edge clamps exactly).  It covers the
-// block's own footprint plus a margin of >= 6 low-res cells (~48 full-res pixels of displacement); taps that
-// fall outside it read global memory instead.
-constexpr int PT_X = 64, PT_Y = 4, PPX = 4;   // 64 x 4 threads, 4 pixels per thread along x
-constexpr int WIN_W = 48, WIN_H = 16, WIN_MX = 7, WIN_MY = 6;
-
-__shared__ float4 win_cells[WIN_H * WIN_W];   // file scope keeps the LDS address space (ds_read, not flat)
-
-struct Win {
-  int wx0, wy0;          // low-res coordinates of cell (0,0)
-  const float* g[4];     // global fallback: fwd.x, fwd.y, bwd.x, bwd.y
-  int h, w;
-};
-
-// Lean axis of the x8 up-sampling for positions inside the image: src = dst*scale < n_in always, so ATen's
-// clamps of i0 and of the weight are no-ops; the +1 neighbour is left to the caller (replicated LDS window,
-// or an explicit clamp on the global path).
+// Lean axis of the x8 up-sampling for positions inside the image: src = dst*scale < n_in always, so ATen's clamps of
+// i0 and of the weight are no-ops; the +1 neighbour comes from a replicate-padded LDS window.
 struct AxF {
   int i0;
   float l0, l1;
@@ -201,297 +195,602 @@ __device__ __forceinline__ AxF axf(int dst, float scale) {
   return a;
 }
 
-// the 2x2 low-res neighbourhood (i0y..i0y+1) x (i0x..i0x+1) from global memory, clamped at the borders
-__device__ __forceinline__ void lo_quad_global(const Win& wn, int i0y, int i0x, float4& a, float4& b, float4& c,
-                                               float4& d) {
-  const int x1 = min(i0x + 1, wn.w - 1), y1 = min(i0y + 1, wn.h - 1);
-  const unsigned o00 = i0y * wn.w + i0x, o01 = i0y * wn.w + x1, o10 = y1 * wn.w + i0x, o11 = y1 * wn.w + x1;
-  a = make_float4(wn.g[0][o00], wn.g[1][o00], wn.g[2][o00], wn.g[3][o00]);
-  b = make_float4(wn.g[0][o01], wn.g[1][o01], wn.g[2][o01], wn.g[3][o01]);
-  c = make_float4(wn.g[0][o10], wn.g[1][o10], wn.g[2][o10], wn.g[3][o10]);
-  d = make_float4(wn.g[0][o11], wn.g[1][o11], wn.g[2][o11], wn.g[3][o11]);
+// Tile / region geometry.  A block of 640 threads (10 waves) owns TX x TY output pixels; the staged region adds HL
+// pixels on the left / top and HR on the right / bottom (one of them is the +1 neighbour of the last tap).
+constexpr int TX = 64, TY = 40, HL = 8, HR = 8;
+constexpr int RW = TX + HL + HR, RH = TY + HL + HR;          // 80 x 56
+constexpr int NGROUP = 8;                                     // row groups of the staging loop
+constexpr int NT = (NGROUP + NGROUP / 4) * 64, NWAVE = NT / 64;   // 8 waves stage the tile columns, 2 the halo columns
+constexpr int ROWS_PER_GROUP = RH / NGROUP;                   // 7 region rows per staging thread
+constexpr int LW_W = RW / 8 + 4, LW_H = RH / 8 + 4;           // low-res window (replicate-padded): 14 x 11 cells
+static_assert(RH % NGROUP == 0 && TY % NWAVE == 0 && (RW - TX) * 4 == 64 && NGROUP % 4 == 0,
+              "thread mapping of the staging loop");
+
+// which region column / first region row a staging thread owns
+__device__ __forceinline__ void stage_slot(int t, int& rc, int& r0) {
+  if (t < NGROUP * 64) {                  // waves 0..NGROUP-1: the 64 tile columns, one row group per wave
+    rc = HL + (t & 63);
+    r0 = (t >> 6) * ROWS_PER_GROUP;
+  } else {                                // the remaining waves: the 16 halo columns x 4 row groups each
+    const int l = t - NGROUP * 64, j = l & 15;
+    rc = j < HL ? j : TX + j;
+    r0 = (l >> 4) * ROWS_PER_GROUP;
+  }
 }
 
-// 16 * (weighted sum) = 2 * upflow8 value: both scalings are exact
-__device__ __forceinline__ float up8_x16(float a, float b, float c, float d, float w00, float w01, float w10, float w11) {
-  float acc = b * w01;
-  acc = __builtin_fmaf(a, w00, acc);
-  acc = __builtin_fmaf(c, w10, acc);
-  acc = __builtin_fmaf(d, w11, acc);
-  return 16.f * acc;
+// slow path of a tap set that leaves the staged region: the generic per-pixel routine over the lazily up-sampled maps
+__device__ __attribute__((noinline)) bool fbc_generic(const float* own, const float* opp, int h, int w, int y, int x,
+                                                      float alpha1, float a2) {
+  const bool sep = up8_separable(h, w);
+  const FetchUp8 fo{own, own + (size_t)h * w, h, w, up8_scale(h), up8_scale(w), sep};
+  const FetchUp8 fp{opp, opp + (size_t)h * w, h, w, up8_scale(h), up8_scale(w), sep};
+  float fx, fy, cx, cy;
+  fo(y, x, fx, fy);
+  return fbc_pixel(fx, fy, fp, 8 * h, 8 * w, y, x, alpha1, a2, 0, cx, cy);
 }
 
-// validity of one pixel given its own flow (fx, fy); OPP selects the opposite direction's channels
-// (0: fwd = .x/.y of the cell, 1: bwd = .z/.w)
-template <int OPP>
-__device__ __forceinline__ bool fbc_up8(float fx, float fy, const Win& wn, const Up8Geom& g, float c0x, float c0y) {
-  const float fnx = div_c(2.f * fx, g.wd), fny = div_c(2.f * fy, g.ht);
-  const float c1x = c0x + fnx, c1y = c0y + fny;
+// validity of one pixel from its own normalised flow fn and the staged normalised flows of the opposite direction
+__device__ __forceinline__ bool fbc_staged(float2 fn, const float2* __restrict__ opp, const Up8Geom& g, float c0x,
+                                           float c0y, int rx0, int ry0, bool& slow) {
+  const float c1x = c0x + fn.x, c1y = c0y + fn.y;
   if (!((fabsf(c1x) < 1.f) && (fabsf(c1y) < 1.f))) return false;
   const float ix = (c1x + 1.f) * g.hx, iy = (c1y + 1.f) * g.hy;
   const float xw = floorf(ix), yn = floorf(iy);
   const float w = ix - xw, e = 1.f - w, n = iy - yn, s = 1.f - n;
-  const int x0 = (int)xw, y0 = (int)yn;
-  // x0+1 == Wf (y0+1 == Hf) only when the weight w (n) is exactly 0: the clamped tap is finite and contributes 0
-  const AxF ax[2] = {axf(x0, g.sx), axf(min(x0 + 1, g.Wf - 1), g.sx)};
-  const AxF ay[2] = {axf(y0, g.sy), axf(min(y0 + 1, g.Hf - 1), g.sy)};
-  const int rx0 = ax[0].i0 - wn.wx0, rx1 = ax[1].i0 - wn.wx0, ry0 = ay[0].i0 - wn.wy0, ry1 = ay[1].i0 - wn.wy0;
-  const bool in_win = (rx0 >= 0) && (rx1 < WIN_W - 1) && (ry0 >= 0) && (ry1 < WIN_H - 1);
-  float tx[4], ty[4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const AxF& vy_ = ay[t >> 1];
-    const AxF& vx_ = ax[t & 1];
-    const float w00 = vy_.l0 * vx_.l0, w01 = vy_.l0 * vx_.l1, w10 = vy_.l1 * vx_.l0, w11 = vy_.l1 * vx_.l1;
-    float4 a, b, c, d;
-    if (__builtin_expect(in_win, 1)) {
-      const int o = ((t >> 1) ? ry1 : ry0) * WIN_W + ((t & 1) ? rx1 : rx0);
-      a = win_cells[o]; b = win_cells[o + 1]; c = win_cells[o + WIN_W]; d = win_cells[o + WIN_W + 1];
-    } else {
-      lo_quad_global(wn, vy_.i0, vx_.i0, a, b, c, d);
-    }
-    tx[t] = div_c(OPP ? up8_x16(a.z, b.z, c.z, d.z, w00, w01, w10, w11)
-                      : up8_x16(a.x, b.x, c.x, d.x, w00, w01, w10, w11), g.wd);
-    ty[t] = div_c(OPP ? up8_x16(a.w, b.w, c.w, d.w, w00, w01, w10, w11)
-                      : up8_x16(a.y, b.y, c.y, d.y, w00, w01, w10, w11), g.ht);
-  }
+  const int rx = (int)xw - rx0, ry = (int)yn - ry0;
+  // x0+1 == Wf (y0+1 == Hf) only when the weight w (n) is exactly 0: the region's clamped duplicate is finite
+  if (!((unsigned)rx < (unsigned)(RW - 1) && (unsigned)ry < (unsigned)(RH - 1))) { slow = true; return false; }
+  const int o = ry * RW + rx;
+  const float2 t0 = opp[o], t1 = opp[o + 1], t2 = opp[o + RW], t3 = opp[o + RW + 1];
   const float nw = s * e, ne = s * w, sw = n * e, se = n * w;
-  const float bx = __builtin_fmaf(tx[3], se, __builtin_fmaf(tx[2], sw, __builtin_fmaf(tx[1], ne, tx[0] * nw)));
-  const float by = __builtin_fmaf(ty[3], se, __builtin_fmaf(ty[2], sw, __builtin_fmaf(ty[1], ne, ty[0] * nw)));
-  const float cx = fnx + bx, cy = fny + by;
+  const float bx = __builtin_fmaf(t3.x, se, __builtin_fmaf(t2.x, sw, __builtin_fmaf(t1.x, ne, t0.x * nw)));
+  const float by = __builtin_fmaf(t3.y, se, __builtin_fmaf(t2.y, sw, __builtin_fmaf(t1.y, ne, t0.y * nw)));
+  const float cx = fn.x + bx, cy = fn.y + by;
   const float cyc = cx * cx + cy * cy;
-  const float eps = g.alpha1 * ((fnx * fnx + fny * fny) + (bx * bx + by * by)) + g.a2;
+  const float eps = g.alpha1 * ((fn.x * fn.x + fn.y * fn.y) + (bx * bx + by * by)) + g.a2;
   return (cyc - eps) <= 0.f;
 }
 
-__global__ void __launch_bounds__(PT_X* PT_Y)
-k_prepare_up8(const float* __restrict__ lo_fwd, const float* __restrict__ lo_bwd, float* __restrict__ flow_fwd,
-              float* __restrict__ flow_bwd, uint8_t* __restrict__ mask_fwd, uint8_t* __restrict__ mask_bwd,
-              int32_t* __restrict__ invalid, int N, Up8Geom g) {
-  const int n = blockIdx.z;
-  const int y = blockIdx.y * PT_Y + threadIdx.y;
-  const int xb = (blockIdx.x * PT_X + threadIdx.x) * PPX;
+// ---- fused file-mode apply_optical_flow, nframe = 2: both composed flows + both masks ------------------------------
+// k_prepare_cert writes the flows of every tile and the masks of every tile it can CERTIFY; the rest it marks for
+// k_prepare_staged.  The certificate: a pixel of direction d is valid iff it stays inside the frame and
+//     |fn + b'|^2 <= alpha1 (|fn|^2 + |b'|^2) + a2,          b' = bilinear sample of the opposite normalised flow,
+// (util.py:276-297).  b' is a convex combination of four up-sampled values, each a convex combination of low-res cells,
+// so it lies in the bounding box [L,U] of the cells its taps can touch.  Which cells those are follows from the pixel's
+// own low-res cell and the range of the tile's own flow (a few cells around the cell the pixel is displaced to); the
+// kernel tabulates that box once per low-res cell of the tile, in LDS, with two separable min/max passes.  Then
+//     |fn + b'| <= max(|fn + L|, |fn + U|) per component (boxes inflated by 1e-5 relative for every rounding on the way;
+//     a correctly rounded division is monotone), and since the right-hand side of the test is >= a2,
+//     max(..)_x^2 + max(..)_y^2 <= a2 (1 - 2e-5)   ==>   valid, whatever the taps are.
+// Pixels inside the frame that are not certified are evaluated exactly (generic path), so the masks are bit-identical
+// either way; the certificate only decides who pays for the taps.  A tile in which the certificate cannot work (own flow
+// range wider than the table reaches, or most boxes wider than the tolerance: motion boundaries, occlusions) is left
+// to the staged kernel.  A certified pixel costs one fused up-sampling step per channel, the exact normalisation and
+// ~12 instructions per direction - no taps, no halo.
+constexpr int TYC = 2 * TY;                              // a certified tile = two staged tiles on top of each other
+constexpr int W0_W = TX / 8 + 4, W0_H = TYC / 8 + 4;     // low-res cells under a tile: at most 12 x 14
+constexpr int MARG = 4;                                  // cells of margin around them: own flows up to ~ +-24 px
+constexpr int WW = W0_W + 2 * MARG, WH = W0_H + 2 * MARG;   // cell window: 20 x 22
+constexpr float BOX_SLOP = 1e-5f;
+constexpr uint8_t TILE_MARK = 0xFF;                      // first mask byte of a tile left to k_prepare_staged
+constexpr int NT_C = 320, NWAVE_C = NT_C / 64, ROWS_C = TYC / NWAVE_C;   // 5 waves x 16 rows, lane = column
+static_assert(TYC % NWAVE_C == 0 && 2 * ROWS_C <= 32, "row mapping / deferred-pixel bit mask");
+
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// [lo, hi] of raw cell values -> box of the normalised up-sampled flow 16*acc/b, inflated for rounding
+__device__ __forceinline__ void norm_box(float lo, float hi, const DivC& d, float& L, float& U) {
+  const float s = BOX_SLOP * fmaxf(fabsf(lo), fabsf(hi));
+  L = div_c(16.f * (lo - s), d);
+  U = div_c(16.f * (hi + s), d);
+  const float s2 = BOX_SLOP * fmaxf(fabsf(L), fabsf(U));
+  L -= s2; U += s2;
+}
+// Cells (relative to the pixel's own cell j, j = int(x*scale)) that the taps of a pixel displaced by [dlo, dhi] pixels
+// can touch.  Tap pixels are x0 = floor(x + f +- 2e-4) and x0 + 1, so x0 in [x + a, x + b] with a = floor(dlo) - 1,
+// b = ceil(dhi) + 1; a pixel q interpolates cells int(q*scale) and that + 1, and x*scale is in [j, j+1).
+__device__ __forceinline__ void cell_offsets(float dlo, float dhi, float scale, int& o_lo, int& o_hi) {
+  const float a = floorf(dlo) - 1.f, b = ceilf(dhi) + 1.f;
+  o_lo = (int)floorf(a * scale - 1e-4f);
+  o_hi = 2 + (int)floorf(b * scale + 1e-4f);
+}
+__device__ __forceinline__ bool uniform(bool b) { return __builtin_amdgcn_readfirstlane((int)b) != 0; }
+
+__global__ void __launch_bounds__(NT_C)
+k_prepare_cert(const float* __restrict__ lo_fwd, const float* __restrict__ lo_bwd, float* __restrict__ flow_fwd,
+               float* __restrict__ flow_bwd, uint8_t* __restrict__ mask_fwd, uint8_t* __restrict__ mask_bwd,
+               int32_t* __restrict__ invalid, int N, Up8Geom g, int force) {
+  __shared__ float4 cw[WH * WW];           // cells {fwd.x, fwd.y, bwd.x, bwd.y} under the tile + margin, replicate-padded
+  __shared__ float4 tmp[2][WH * W0_W];     // row pass {min x, max x, min y, max y} of the opposite flow
+  __shared__ float4 tab[2][W0_H * W0_W];   // per own cell: normalised, inflated box {Lx, Ux, Ly, Uy} of the opposite flow
+  __shared__ float part0[NWAVE_C][8];      // per-wave {min, max} x 4 channels of the cells under the tile
+  __shared__ int odd_cells, wide_boxes;    // NaN / infinite cell seen (fminf would drop a NaN); boxes beyond the tolerance
+  const int n = blockIdx.z, t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int tx0 = blockIdx.x * TX, ty0 = blockIdx.y * TYC;
+  const int tx1 = min(tx0 + TX, g.Wf) - 1, ty1 = min(ty0 + TYC, g.Hf) - 1;     // last pixel of the tile inside the frame
   const size_t hw = (size_t)g.h * g.w, HW = (size_t)g.Hf * g.Wf;
-  Win wn;
-  wn.g[0] = lo_fwd + (size_t)n * 2 * hw; wn.g[1] = wn.g[0] + hw;
-  wn.g[2] = lo_bwd + (size_t)n * 2 * hw; wn.g[3] = wn.g[2] + hw;
-  wn.h = g.h; wn.w = g.w;
-  wn.wx0 = up8_axis(blockIdx.x * PT_X * PPX, g.w, g.sx).i0 - WIN_MX;
-  wn.wy0 = up8_axis(blockIdx.y * PT_Y, g.h, g.sy).i0 - WIN_MY;
-  for (int e = threadIdx.y * PT_X + threadIdx.x; e < WIN_H * WIN_W; e += PT_X * PT_Y) {
-    const int r = e / WIN_W, c = e % WIN_W;
-    const unsigned o = min(max(wn.wy0 + r, 0), g.h - 1) * g.w + min(max(wn.wx0 + c, 0), g.w - 1);
-    win_cells[e] = make_float4(wn.g[0][o], wn.g[1][o], wn.g[2][o], wn.g[3][o]);
+  const float* gf = lo_fwd + (size_t)n * 2 * hw;
+  const float* gb = lo_bwd + (size_t)n * 2 * hw;
+  const float INF = __builtin_huge_valf();
+  // ---- the cell window and the range of the tile's own flows
+  const int wx0 = axf(tx0, g.sx).i0, wy0 = axf(ty0, g.sy).i0;
+  const int ucols = min(axf(tx1, g.sx).i0 + 1, g.w - 1) - wx0 + 1, urows = min(axf(ty1, g.sy).i0 + 1, g.h - 1) - wy0 + 1;
+  if (t == 0) { odd_cells = 0; wide_boxes = 0; }
+  {
+    float mn[4] = {INF, INF, INF, INF}, mx[4] = {-INF, -INF, -INF, -INF};
+    bool odd = false;
+    for (int e = t; e < WH * WW; e += NT_C) {
+      const int r = e / WW, c = e - r * WW;
+      const unsigned o = min(max(wy0 - MARG + r, 0), g.h - 1) * g.w + min(max(wx0 - MARG + c, 0), g.w - 1);
+      const float4 v = make_float4(gf[o], gf[hw + o], gb[o], gb[hw + o]);
+      cw[e] = v;
+      odd = odd || !(fabsf(v.x) < INF && fabsf(v.y) < INF && fabsf(v.z) < INF && fabsf(v.w) < INF);
+      if ((unsigned)(r - MARG) < (unsigned)urows && (unsigned)(c - MARG) < (unsigned)ucols) {
+        mn[0] = fminf(mn[0], v.x); mn[1] = fminf(mn[1], v.y); mn[2] = fminf(mn[2], v.z); mn[3] = fminf(mn[3], v.w);
+        mx[0] = fmaxf(mx[0], v.x); mx[1] = fmaxf(mx[1], v.y); mx[2] = fmaxf(mx[2], v.z); mx[3] = fmaxf(mx[3], v.w);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float a = wave_min(mn[k]), b = wave_max(mx[k]);
+      if (lane == 0) { part0[wave][2 * k] = a; part0[wave][2 * k + 1] = b; }
+    }
+    if (__any(odd) && lane == 0) odd_cells = 1;
   }
   __syncthreads();
-  int badf = 0, badb = 0;
-  if (y < g.Hf && xb < g.Wf) {
+  bool certify = mask_fwd != nullptr && force != 2;       // block-uniform throughout
+  if (mask_fwd != nullptr) {                              // uniform: the barriers below are reached by every thread
+    int ox[2] = {0, 0}, oy[2] = {0, 0}, ex[2] = {0, 0}, ey[2] = {0, 0};    // first / last cell offset per axis, per direction
+    certify = certify && odd_cells == 0;
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      float lo[2], hi[2];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        float l = part0[0][4 * d + 2 * k], h = part0[0][4 * d + 2 * k + 1];
+#pragma unroll
+        for (int wv = 1; wv < NWAVE_C; ++wv) { l = fminf(l, part0[wv][4 * d + 2 * k]); h = fmaxf(h, part0[wv][4 * d + 2 * k + 1]); }
+        const float s = BOX_SLOP * fmaxf(fabsf(l), fabsf(h));
+        lo[k] = 8.f * (l - s); hi[k] = 8.f * (h + s);      // own flow of direction d in pixels
+        certify = certify && (hi[k] - lo[k] <= 64.f * MARG);                 // false for NaN too; bounds the casts below
+      }
+      if (certify) {
+        cell_offsets(lo[0], hi[0], g.sx, ox[d], ex[d]);
+        cell_offsets(lo[1], hi[1], g.sy, oy[d], ey[d]);
+        // the neighbourhood of every cell under the tile has to lie inside the window
+        certify = ox[d] >= -MARG && ex[d] <= MARG + (W0_W - ucols) && oy[d] >= -MARG && ey[d] <= MARG + (W0_H - urows);
+      }
+    }
+    certify = uniform(certify);
+    if (certify) {                                        // row pass: min / max over cells j + ox .. j + ex of each row
+      for (int e = t; e < 2 * WH * W0_W; e += NT_C) {
+        const int d = e >= WH * W0_W, q = e - d * WH * W0_W, r = q / W0_W, j = q - r * W0_W;
+        if (r >= MARG + oy[d] && r <= MARG + urows - 1 + ey[d] && j < ucols) {
+          float4 m = make_float4(INF, -INF, INF, -INF);
+          for (int k = ox[d]; k <= ex[d]; ++k) {
+            const float4 v = cw[r * WW + MARG + j + k];
+            const float vx = d ? v.x : v.z, vy = d ? v.y : v.w;          // fwd pixels (d = 0) sample the bwd flow
+            m.x = fminf(m.x, vx); m.y = fmaxf(m.y, vx); m.z = fminf(m.z, vy); m.w = fmaxf(m.w, vy);
+          }
+          tmp[d][q] = m;
+        }
+      }
+    }
+    __syncthreads();
+    if (certify) {                                        // column pass -> normalised boxes
+      for (int e = t; e < 2 * W0_H * W0_W; e += NT_C) {
+        const int d = e >= W0_H * W0_W, q = e - d * W0_H * W0_W, i = q / W0_W, j = q - i * W0_W;
+        if (i < urows && j < ucols) {
+          float4 m = make_float4(INF, -INF, INF, -INF);
+          for (int k = oy[d]; k <= ey[d]; ++k) {
+            const float4 v = tmp[d][(MARG + i + k) * W0_W + j];
+            m.x = fminf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fminf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+          }
+          float4 b;
+          norm_box(m.x, m.y, g.wd, b.x, b.y);
+          norm_box(m.z, m.w, g.ht, b.z, b.w);
+          tab[d][q] = b;
+          const float wxb = b.y - b.x, wyb = b.w - b.z;
+          if (!(wxb * wxb + wyb * wyb <= g.a2)) atomicAdd(&wide_boxes, 1);   // cannot certify anything
+        }
+      }
+    }
+    __syncthreads();
+    // most boxes beyond the tolerance: the generic per-pixel fallback would dominate; the staged kernel is cheaper
+    if (force != 1) certify = certify && 4 * wide_boxes <= 2 * urows * ucols;
+    certify = uniform(certify);
+    if (!certify && t < 2 && ty0 + t * TY < g.Hf)          // both staged tiles under this one
+      mask_fwd[(size_t)n * HW + (size_t)(ty0 + t * TY) * g.Wf + tx0] = TILE_MARK;
+  }
+  const float a2c = g.a2 * (1.f - 2.f * BOX_SLOP);
+  // ---- the pixels: lane = column, each wave walks ROWS_C rows; separable up-sampling as in the staged kernel
+  const int x = tx0 + lane;
+  const bool act = x < g.Wf;
+  const AxF ax = axf(min(x, g.Wf - 1), g.sx);
+  const int cxi = ax.i0 - wx0;
+  const float c0x = div_c(2.f * (float)x, g.wd) - 1.f;
+  float4 t0 = make_float4(0.f, 0.f, 0.f, 0.f), t1 = t0, bxf = t0, bxb = t0;   // bxf: bwd-flow box for fwd pixels
+  int have = -2, badf = 0, badb = 0;                           // bad counts are wave-uniform
+  unsigned undecided = 0;                                      // bit 2*rr + d: inside the frame but not certified
+  float* of = flow_fwd + (size_t)n * 2 * HW + x;
+  float* ob = flow_bwd + (size_t)n * 2 * HW + x;
+  const int yw = ty0 + wave * ROWS_C;
+  for (int rr = 0; rr < ROWS_C; ++rr) {
+    const int y = yw + rr;
+    if (y >= g.Hf) break;                                      // wave-uniform
     const AxF ay = axf(y, g.sy);
-    const int ory = (ay.i0 - wn.wy0) * WIN_W - wn.wx0;
+    if (ay.i0 != have) {
+      const float4* cell = cw + (MARG + ay.i0 - wy0) * WW + MARG + cxi;
+      if (ay.i0 == have + 1) {
+        t0 = t1;
+      } else {
+        const float4 a = cell[0], b = cell[1];
+        t0 = make_float4(up8_row(a.x, b.x, ax.l0, ax.l1), up8_row(a.y, b.y, ax.l0, ax.l1),
+                         up8_row(a.z, b.z, ax.l0, ax.l1), up8_row(a.w, b.w, ax.l0, ax.l1));
+      }
+      const float4 c = cell[WW], d = cell[WW + 1];
+      t1 = make_float4(up8_row(c.x, d.x, ax.l0, ax.l1), up8_row(c.y, d.y, ax.l0, ax.l1),
+                       up8_row(c.z, d.z, ax.l0, ax.l1), up8_row(c.w, d.w, ax.l0, ax.l1));
+      if (certify) {
+        const int ci = (ay.i0 - wy0) * W0_W + cxi;
+        bxf = tab[0][ci]; bxb = tab[1][ci];
+      }
+      have = ay.i0;
+    }
+    // 16 * (interpolated value) = 2 * upflow8 value; both scalings are exact
+    const float fx16 = 16.f * up8_col(t0.x, t1.x, ay.l0, ay.l1), fy16 = 16.f * up8_col(t0.y, t1.y, ay.l0, ay.l1);
+    const float bx16 = 16.f * up8_col(t0.z, t1.z, ay.l0, ay.l1), by16 = 16.f * up8_col(t0.w, t1.w, ay.l0, ay.l1);
+    const size_t q = (size_t)y * g.Wf;
+    if (act) {
+      of[q] = 0.5f * fx16; of[HW + q] = 0.5f * fy16;
+      ob[q] = 0.5f * bx16; ob[HW + q] = 0.5f * by16;
+    }
+    if (!certify) continue;                                    // block-uniform
     const float c0y = div_c(2.f * (float)y, g.ht) - 1.f;
-    float ffx[PPX], ffy[PPX], fbx[PPX], fby[PPX];
-    uint8_t mf[PPX], mb[PPX];
+    const float fn[2][2] = {{div_c(fx16, g.wd), div_c(fy16, g.ht)}, {div_c(bx16, g.wd), div_c(by16, g.ht)}};
+    bool ok[2];
 #pragma unroll
-    for (int i = 0; i < PPX; ++i) {
-      const int x = min(xb + i, g.Wf - 1);
-      const AxF ax = axf(x, g.sx);
-      const float w00 = ay.l0 * ax.l0, w01 = ay.l0 * ax.l1, w10 = ay.l1 * ax.l0, w11 = ay.l1 * ax.l1;
-      const int o = ory + ax.i0;                       // the block's own footprint is inside the window
-      const float4 a = win_cells[o], b = win_cells[o + 1], c = win_cells[o + WIN_W], d = win_cells[o + WIN_W + 1];
-      const float fx = 0.5f * up8_x16(a.x, b.x, c.x, d.x, w00, w01, w10, w11);
-      const float fy = 0.5f * up8_x16(a.y, b.y, c.y, d.y, w00, w01, w10, w11);
-      const float bx = 0.5f * up8_x16(a.z, b.z, c.z, d.z, w00, w01, w10, w11);
-      const float by = 0.5f * up8_x16(a.w, b.w, c.w, d.w, w00, w01, w10, w11);
-      ffx[i] = fx; ffy[i] = fy; fbx[i] = bx; fby[i] = by;
-      mf[i] = mb[i] = 0;
-      if (mask_fwd) {
-        const float c0x = div_c(2.f * (float)x, g.wd) - 1.f;
-        mf[i] = fbc_up8<1>(fx, fy, wn, g, c0x, c0y) ? 1 : 0;
-        mb[i] = fbc_up8<0>(bx, by, wn, g, c0x, c0y) ? 1 : 0;
-        if (xb + i < g.Wf) { badf += 1 - mf[i]; badb += 1 - mb[i]; }
-      }
+    for (int d = 0; d < 2; ++d) {
+      const float4 bx = d ? bxb : bxf;
+      const float c1x = c0x + fn[d][0], c1y = c0y + fn[d][1];
+      const bool inside = (fabsf(c1x) < 1.f) && (fabsf(c1y) < 1.f);
+      const float mx = fmaxf(fabsf(fn[d][0] + bx.x), fabsf(fn[d][0] + bx.y));
+      const float my = fmaxf(fabsf(fn[d][1] + bx.z), fabsf(fn[d][1] + bx.w));
+      const bool sure = __builtin_fmaf(mx, mx, my * my) <= a2c;
+      ok[d] = inside && sure;
+      if (inside && !sure) undecided |= 1u << (2 * rr + d);   // settled exactly after the loop
     }
-    const size_t r = (size_t)y * g.Wf + xb;
-    float* pf = flow_fwd + (size_t)n * 2 * HW + r;
-    float* pb = flow_bwd + (size_t)n * 2 * HW + r;
-    if (xb + PPX <= g.Wf && (g.Wf & 3) == 0) {
-      *reinterpret_cast<float4*>(pf) = make_float4(ffx[0], ffx[1], ffx[2], ffx[3]);
-      *reinterpret_cast<float4*>(pf + HW) = make_float4(ffy[0], ffy[1], ffy[2], ffy[3]);
-      *reinterpret_cast<float4*>(pb) = make_float4(fbx[0], fbx[1], fbx[2], fbx[3]);
-      *reinterpret_cast<float4*>(pb + HW) = make_float4(fby[0], fby[1], fby[2], fby[3]);
-      if (mask_fwd) {
-        *reinterpret_cast<uchar4*>(mask_fwd + (size_t)n * HW + r) = make_uchar4(mf[0], mf[1], mf[2], mf[3]);
-        *reinterpret_cast<uchar4*>(mask_bwd + (size_t)n * HW + r) = make_uchar4(mb[0], mb[1], mb[2], mb[3]);
-      }
-    } else {
-      for (int i = 0; i < PPX && xb + i < g.Wf; ++i) {
-        pf[i] = ffx[i]; pf[HW + i] = ffy[i]; pb[i] = fbx[i]; pb[HW + i] = fby[i];
-        if (mask_fwd) { mask_fwd[(size_t)n * HW + r + i] = mf[i]; mask_bwd[(size_t)n * HW + r + i] = mb[i]; }
-      }
+    if (act) {
+      mask_fwd[(size_t)n * HW + q + x] = ok[0] ? 1 : 0;
+      mask_bwd[(size_t)n * HW + q + x] = ok[1] ? 1 : 0;
     }
+    badf += __popcll(__ballot(act && !ok[0]));
+    badb += __popcll(__ballot(act && !ok[1]));
   }
-  if (invalid) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { badf += __shfl_xor(badf, o, 64); badb += __shfl_xor(badb, o, 64); }
-    if (threadIdx.x == 0) {
-      if (badf) atomicAdd(&invalid[n], badf);
-      if (badb) atomicAdd(&invalid[N + n], badb);
+  // pixels the certificate could not settle: the exact generic evaluation (kept out of the loop above so that the call
+  // does not dictate its register allocation)
+  if (!act) undecided = 0;
+  while (__any(undecided != 0)) {
+    bool fixed_f = false, fixed_b = false;
+    if (undecided) {
+      const int bit = __builtin_ctz(undecided);
+      undecided &= undecided - 1;
+      const int d = bit & 1, y = yw + (bit >> 1);
+      if (fbc_generic(d ? gb : gf, d ? gf : gb, g.h, g.w, y, x, g.alpha1, g.a2)) {
+        (d ? mask_bwd : mask_fwd)[(size_t)n * HW + (size_t)y * g.Wf + x] = 1;
+        fixed_f = d == 0; fixed_b = d == 1;
+      }
     }
+    badf -= __popcll(__ballot(fixed_f));
+    badb -= __popcll(__ballot(fixed_b));
+  }
+  if (invalid && certify && lane == 0) {
+    if (badf) atomicAdd(&invalid[n], badf);
+    if (badb) atomicAdd(&invalid[N + n], badb);
   }
 }
 
-// ---- multi-frame (F-1 > 1) production kernels -----------------------------------------------------
-// k_chain_up8: concat_flow over lazily up-sampled 1/8-resolution maps.  Same tiling / LDS-window / exact
-// constant-division scheme as k_prepare_up8; one window per flow of the chain (float2 cells), direction in
-// blockIdx.z.  A chain that drifts out of its block's window reads global memory; a tap that leaves the frame
-// contributes zero (grid_sample zeros padding).
-constexpr int CH_MAXF = 6;       // windows kept in LDS: 6 * 48 * 16 * 8 B = 36 KB
-__shared__ float2 chain_cells[CH_MAXF * WIN_H * WIN_W];
-
-__device__ __forceinline__ void chain_quad(const float* __restrict__ gx, const float* __restrict__ gy, int t, int wx0,
-                                           int wy0, int h, int w, int i0y, int i0x, float2& a, float2& b, float2& c,
-                                           float2& d) {
-  const int ry = i0y - wy0, rx = i0x - wx0;
-  if (__builtin_expect((unsigned)ry < (unsigned)(WIN_H - 1) && (unsigned)rx < (unsigned)(WIN_W - 1), 1)) {
-    const int o = (t * WIN_H + ry) * WIN_W + rx;
-    a = chain_cells[o]; b = chain_cells[o + 1]; c = chain_cells[o + WIN_W]; d = chain_cells[o + WIN_W + 1];
-  } else {
-    const int x1 = min(i0x + 1, w - 1), y1 = min(i0y + 1, h - 1);
-    const unsigned o00 = i0y * w + i0x, o01 = i0y * w + x1, o10 = y1 * w + i0x, o11 = y1 * w + x1;
-    a = make_float2(gx[o00], gy[o00]); b = make_float2(gx[o01], gy[o01]);
-    c = make_float2(gx[o10], gy[o10]); d = make_float2(gx[o11], gy[o11]);
+// ---- second launch of the nframe = 2 preparation: the masks of the tiles the certified kernel could not settle -------
+// (flows that vary by more than the certificate tolerates inside a tile: motion boundaries, occlusions).  Taps come from
+// LDS; the flows themselves were already written by k_prepare_cert.
+__global__ void __launch_bounds__(NT)
+k_prepare_staged(const float* __restrict__ lo_fwd, const float* __restrict__ lo_bwd, uint8_t* __restrict__ mask_fwd,
+                 uint8_t* __restrict__ mask_bwd, int32_t* __restrict__ invalid, int N, Up8Geom g, int tiles_x,
+                 int tiles_y) {
+  __shared__ float2 nf[RH * RW];           // normalised forward flow of the region
+  __shared__ float2 nb[RH * RW];           // normalised backward flow
+  __shared__ float4 lw[LW_H * LW_W];       // low-res cells {fwd.x, fwd.y, bwd.x, bwd.y}, replicate-padded
+  // few tiles are marked, so the grid is small and every block scans its share of the tile list (an empty launch of
+  // one block per tile cost 0.17 ms at N = 256)
+  const int t = threadIdx.x;
+  const size_t hw = (size_t)g.h * g.w, HW = (size_t)g.Hf * g.Wf;
+  const int ntiles = tiles_x * tiles_y * N;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  const int n = tile / (tiles_x * tiles_y), rem = tile - n * tiles_x * tiles_y, by = rem / tiles_x, bx = rem - by * tiles_x;
+  const int tx0 = bx * TX, ty0 = by * TY;
+  const int rx0 = tx0 - HL, ry0 = ty0 - HL;
+  // every thread reads the mark before the first barrier; the first mask byte is written after the second one
+  if (mask_fwd[(size_t)n * HW + (size_t)ty0 * g.Wf + tx0] != TILE_MARK) continue;      // block-uniform
+  const float* gf = lo_fwd + (size_t)n * 2 * hw;
+  const float* gb = lo_bwd + (size_t)n * 2 * hw;
+  // low-res window: first cell = the cell of the region's first (clamped) pixel
+  const int wx0 = axf(max(rx0, 0), g.sx).i0, wy0 = axf(max(ry0, 0), g.sy).i0;
+  for (int e = t; e < LW_H * LW_W; e += NT) {
+    const int r = e / LW_W, c = e - r * LW_W;
+    const unsigned o = min(wy0 + r, g.h - 1) * g.w + min(wx0 + c, g.w - 1);
+    lw[e] = make_float4(gf[o], gf[hw + o], gb[o], gb[hw + o]);
+  }
+  __syncthreads();
+  {
+    int rc, r0;
+    stage_slot(t, rc, r0);
+    const int x = min(max(rx0 + rc, 0), g.Wf - 1);
+    const AxF ax = axf(x, g.sx);
+    const int cx = ax.i0 - wx0;
+    float4 t0 = make_float4(0.f, 0.f, 0.f, 0.f), t1 = t0;    // x-interpolated source rows i0y, i0y+1
+    int have = -2;
+#pragma unroll 2
+    for (int r = r0; r < r0 + ROWS_PER_GROUP; ++r) {
+      const int y = min(max(ry0 + r, 0), g.Hf - 1);
+      const AxF ay = axf(y, g.sy);
+      if (ay.i0 != have) {
+        const float4* cell = lw + (ay.i0 - wy0) * LW_W + cx;
+        if (ay.i0 == have + 1) {
+          t0 = t1;
+        } else {
+          const float4 a = cell[0], b = cell[1];
+          t0 = make_float4(up8_row(a.x, b.x, ax.l0, ax.l1), up8_row(a.y, b.y, ax.l0, ax.l1),
+                           up8_row(a.z, b.z, ax.l0, ax.l1), up8_row(a.w, b.w, ax.l0, ax.l1));
+        }
+        const float4 c = cell[LW_W], d = cell[LW_W + 1];
+        t1 = make_float4(up8_row(c.x, d.x, ax.l0, ax.l1), up8_row(c.y, d.y, ax.l0, ax.l1),
+                         up8_row(c.z, d.z, ax.l0, ax.l1), up8_row(c.w, d.w, ax.l0, ax.l1));
+        have = ay.i0;
+      }
+      // 16 * (interpolated value) = 2 * upflow8 value; both scalings are exact
+      const float fx16 = 16.f * up8_col(t0.x, t1.x, ay.l0, ay.l1), fy16 = 16.f * up8_col(t0.y, t1.y, ay.l0, ay.l1);
+      const float bx16 = 16.f * up8_col(t0.z, t1.z, ay.l0, ay.l1), by16 = 16.f * up8_col(t0.w, t1.w, ay.l0, ay.l1);
+      nf[r * RW + rc] = make_float2(div_c(fx16, g.wd), div_c(fy16, g.ht));
+      nb[r * RW + rc] = make_float2(div_c(bx16, g.wd), div_c(by16, g.ht));
+    }
+  }
+  __syncthreads();
+  const int wave = t >> 6, lane = t & 63;
+  const int x = tx0 + lane;
+  const float c0x = div_c(2.f * (float)x, g.wd) - 1.f;
+  int badf = 0, badb = 0;
+#pragma unroll 2
+  for (int rr = 0; rr < TY / NWAVE; ++rr) {
+    const int ty = wave * (TY / NWAVE) + rr, y = ty0 + ty;
+    if (y >= g.Hf) break;                                   // wave-uniform
+    bool okf = true, okb = true;
+    if (x < g.Wf) {
+      const int o = (ty + HL) * RW + (lane + HL);
+      const float c0y = div_c(2.f * (float)y, g.ht) - 1.f;
+      bool slowf = false, slowb = false;
+      okf = fbc_staged(nf[o], nb, g, c0x, c0y, rx0, ry0, slowf);
+      okb = fbc_staged(nb[o], nf, g, c0x, c0y, rx0, ry0, slowb);
+      if (__builtin_expect(slowf, 0)) okf = fbc_generic(gf, gb, g.h, g.w, y, x, g.alpha1, g.a2);
+      if (__builtin_expect(slowb, 0)) okb = fbc_generic(gb, gf, g.h, g.w, y, x, g.alpha1, g.a2);
+      const size_t q = (size_t)n * HW + (size_t)y * g.Wf + x;
+      mask_fwd[q] = okf ? 1 : 0;
+      mask_bwd[q] = okb ? 1 : 0;
+    }
+    badf += __popcll(__ballot(!okf));
+    badb += __popcll(__ballot(!okb));
+  }
+  if (invalid && lane == 0) {
+    if (badf) atomicAdd(&invalid[n], badf);
+    if (badb) atomicAdd(&invalid[N + n], badb);
+  }
+  __syncthreads();                                          // the LDS images are reused by the next tile
   }
 }
 
-__global__ void __launch_bounds__(PT_X* PT_Y)
+// ---- multi-frame (F-1 > 1): concat_flow over lazily up-sampled maps, both directions in one launch -----------------
+// One chain per pixel, advanced one flow at a time by the whole block: for flow t the block stages the up-sampled map
+// U_t (pixel units) over a region around where its chains currently ARE - the tile displaced by the block's mean drift
+// so far, so the halo only has to cover how much the drift varies inside a tile, not how large it is - and every chain
+// takes its four bilinear taps from LDS (zeros padding: taps outside the frame contribute 0, util.py:318-323).
+constexpr int CH_PX = TY / NWAVE;        // chains per thread: lane = x, CH_PX rows per wave
+
+__device__ __attribute__((noinline)) void chain_step_generic(const float* lo_t, int h, int w, float cx, float cy,
+                                                             float& fx, float& fy) {
+  const int Hf = 8 * h, Wf = 8 * w;
+  const FetchUp8 f{lo_t, lo_t + (size_t)h * w, h, w, up8_scale(h), up8_scale(w), up8_separable(h, w)};
+  bilinear2(f, Hf, Wf, 2.f * cx / (float)(Wf - 1) - 1.f, 2.f * cy / (float)(Hf - 1) - 1.f, TapNone(), fx, fy);
+}
+
+__global__ void __launch_bounds__(NT)
 k_chain_up8(const float* __restrict__ lo_fwd, const float* __restrict__ lo_bwd, float* __restrict__ flow_fwd,
             float* __restrict__ flow_bwd, int N, int F1, Up8Geom g) {
-  const int n = blockIdx.z >> 1, dir = blockIdx.z & 1;
-  const float* lo = (dir ? lo_bwd : lo_fwd) + (size_t)n * F1 * 2 * g.h * g.w;   // [F1][2][h][w]
-  float* out = (dir ? flow_bwd : flow_fwd) + (size_t)n * 2 * g.Hf * g.Wf;
+  __shared__ float2 u[RH * RW];            // U_t over the current region, pixel units
+  __shared__ float2 lw[LW_H * LW_W];       // low-res cells of flow t, replicate-padded
+  __shared__ float red[NWAVE][3];          // per-wave drift sums {dx, dy, count}
+  const int n = blockIdx.z >> 1, dir = blockIdx.z & 1, t = threadIdx.x;
   const size_t hw = (size_t)g.h * g.w, HW = (size_t)g.Hf * g.Wf;
-  const int y = blockIdx.y * PT_Y + threadIdx.y;
-  const int xb = (blockIdx.x * PT_X + threadIdx.x) * PPX;
-  const int wx0 = axf(blockIdx.x * PT_X * PPX, g.sx).i0 - WIN_MX;
-  const int wy0 = axf(blockIdx.y * PT_Y, g.sy).i0 - WIN_MY;
-  for (int e = threadIdx.y * PT_X + threadIdx.x; e < F1 * WIN_H * WIN_W; e += PT_X * PT_Y) {
-    const int t = e / (WIN_H * WIN_W), r = (e / WIN_W) % WIN_H, c = e % WIN_W;
-    const unsigned o = min(max(wy0 + r, 0), g.h - 1) * g.w + min(max(wx0 + c, 0), g.w - 1);
-    chain_cells[e] = make_float2(lo[(size_t)t * 2 * hw + o], lo[(size_t)t * 2 * hw + hw + o]);
-  }
-  __syncthreads();
-  if (y >= g.Hf || xb >= g.Wf) return;
-  float ox[PPX], oy[PPX];
+  const float* lo = (dir ? lo_bwd : lo_fwd) + (size_t)n * F1 * 2 * hw;          // [F1][2][h][w]
+  float* out = (dir ? flow_bwd : flow_fwd) + (size_t)n * 2 * HW;
+  const int tx0 = blockIdx.x * TX, ty0 = blockIdx.y * TY;
+  const int wave = t >> 6, lane = t & 63;
+  const int x = tx0 + lane;
+  const float x0f = (float)x;
+  float cx[CH_PX], cy[CH_PX];
 #pragma unroll
-  for (int i = 0; i < PPX; ++i) {
-    const int x = min(xb + i, g.Wf - 1);
-    const float x0f = (float)x, y0f = (float)y;
-    float cx = x0f, cy = y0f;
-    for (int t = 0; t < F1; ++t) {
-      const float* gx = lo + (size_t)t * 2 * hw;
-      const float* gy = gx + hw;
-      const float nx = div_c(2.f * cx, g.wd) - 1.f, ny = div_c(2.f * cy, g.ht) - 1.f;   // normalize_coord
-      const float ix = (nx + 1.f) * g.hx, iy = (ny + 1.f) * g.hy;
-      const float xw = floorf(ix), yn = floorf(iy);
-      const float w = ix - xw, e = 1.f - w, nn = iy - yn, s = 1.f - nn;
-      const int tx0 = (xw > -2.f && xw < (float)(g.Wf + 1)) ? (int)xw : -2;
-      const int ty0 = (yn > -2.f && yn < (float)(g.Hf + 1)) ? (int)yn : -2;
-      const bool vx[2] = {tx0 >= 0 && tx0 < g.Wf, tx0 + 1 >= 0 && tx0 + 1 < g.Wf};
-      const bool vy[2] = {ty0 >= 0 && ty0 < g.Hf, ty0 + 1 >= 0 && ty0 + 1 < g.Hf};
-      const AxF ax[2] = {axf(min(max(tx0, 0), g.Wf - 1), g.sx), axf(min(max(tx0 + 1, 0), g.Wf - 1), g.sx)};
-      const AxF ay[2] = {axf(min(max(ty0, 0), g.Hf - 1), g.sy), axf(min(max(ty0 + 1, 0), g.Hf - 1), g.sy)};
-      float tvx[4], tvy[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const AxF& qy = ay[k >> 1];
-        const AxF& qx = ax[k & 1];
-        const float w00 = qy.l0 * qx.l0, w01 = qy.l0 * qx.l1, w10 = qy.l1 * qx.l0, w11 = qy.l1 * qx.l1;
-        float2 a, b, c, d;
-        chain_quad(gx, gy, t, wx0, wy0, g.h, g.w, qy.i0, qx.i0, a, b, c, d);
-        const bool ok = vx[k & 1] && vy[k >> 1];
-        tvx[k] = ok ? 0.5f * up8_x16(a.x, b.x, c.x, d.x, w00, w01, w10, w11) : 0.f;
-        tvy[k] = ok ? 0.5f * up8_x16(a.y, b.y, c.y, d.y, w00, w01, w10, w11) : 0.f;
-      }
-      const float nw = s * e, ne = s * w, sw = nn * e, se = nn * w;
-      const float fx = __builtin_fmaf(tvx[3], se, __builtin_fmaf(tvx[2], sw, __builtin_fmaf(tvx[1], ne, tvx[0] * nw)));
-      const float fy = __builtin_fmaf(tvy[3], se, __builtin_fmaf(tvy[2], sw, __builtin_fmaf(tvy[1], ne, tvy[0] * nw)));
-      cx = cx + fx; cy = cy + fy;
+  for (int i = 0; i < CH_PX; ++i) { cx[i] = x0f; cy[i] = (float)(ty0 + wave * CH_PX + i); }
+  int shx = 0, shy = 0;                    // region displacement = rounded mean drift of the block's chains
+  int rc, r0;
+  stage_slot(t, rc, r0);
+  for (int f = 0; f < F1; ++f) {
+    const float* gx = lo + (size_t)f * 2 * hw;
+    const float* gy = gx + hw;
+    // keep the region on the frame: a region wholly outside it could serve no tap anyway
+    const int rx0 = min(max(tx0 - HL + shx, -HL), g.Wf - 1 - HL), ry0 = min(max(ty0 - HL + shy, -HL), g.Hf - 1 - HL);
+    const int wx0 = axf(max(rx0, 0), g.sx).i0, wy0 = axf(max(ry0, 0), g.sy).i0;
+    for (int e = t; e < LW_H * LW_W; e += NT) {
+      const int r = e / LW_W, c = e - r * LW_W;
+      const unsigned o = min(wy0 + r, g.h - 1) * g.w + min(wx0 + c, g.w - 1);
+      lw[e] = make_float2(gx[o], gy[o]);
     }
-    ox[i] = cx - x0f; oy[i] = cy - y0f;
+    __syncthreads();
+    {
+      const AxF ax = axf(min(max(rx0 + rc, 0), g.Wf - 1), g.sx);
+      const int cxi = ax.i0 - wx0;
+      float2 t0 = make_float2(0.f, 0.f), t1 = t0;
+      int have = -2;
+#pragma unroll 2
+      for (int r = r0; r < r0 + ROWS_PER_GROUP; ++r) {
+        const AxF ay = axf(min(max(ry0 + r, 0), g.Hf - 1), g.sy);
+        if (ay.i0 != have) {
+          const float2* cell = lw + (ay.i0 - wy0) * LW_W + cxi;
+          if (ay.i0 == have + 1) {
+            t0 = t1;
+          } else {
+            const float2 a = cell[0], b = cell[1];
+            t0 = make_float2(up8_row(a.x, b.x, ax.l0, ax.l1), up8_row(a.y, b.y, ax.l0, ax.l1));
+          }
+          const float2 c = cell[LW_W], d = cell[LW_W + 1];
+          t1 = make_float2(up8_row(c.x, d.x, ax.l0, ax.l1), up8_row(c.y, d.y, ax.l0, ax.l1));
+          have = ay.i0;
+        }
+        u[r * RW + rc] = make_float2(8.f * up8_col(t0.x, t1.x, ay.l0, ay.l1), 8.f * up8_col(t0.y, t1.y, ay.l0, ay.l1));
+      }
+    }
+    __syncthreads();
+    float sdx = 0.f, sdy = 0.f, cnt = 0.f;
+#pragma unroll
+    for (int i = 0; i < CH_PX; ++i) {
+      const int y = ty0 + wave * CH_PX + i;
+      if (y < g.Hf && x < g.Wf) {
+        const float nx = div_c(2.f * cx[i], g.wd) - 1.f, ny = div_c(2.f * cy[i], g.ht) - 1.f;   // normalize_coord
+        const float ix = (nx + 1.f) * g.hx, iy = (ny + 1.f) * g.hy;
+        const float xw = floorf(ix), yn = floorf(iy);
+        const float w = ix - xw, e = 1.f - w, nn = iy - yn, s = 1.f - nn;
+        const int px0 = (xw > -2.f && xw < (float)(g.Wf + 1)) ? (int)xw : -2;
+        const int py0 = (yn > -2.f && yn < (float)(g.Hf + 1)) ? (int)yn : -2;
+        const bool vx0 = px0 >= 0 && px0 < g.Wf, vx1 = px0 + 1 >= 0 && px0 + 1 < g.Wf;
+        const bool vy0 = py0 >= 0 && py0 < g.Hf, vy1 = py0 + 1 >= 0 && py0 + 1 < g.Hf;
+        // region coordinates of the taps that count (clamped to the frame: a clamped tap outside it is discarded)
+        const int qx0 = min(max(px0, 0), g.Wf - 1) - rx0, qx1 = min(max(px0 + 1, 0), g.Wf - 1) - rx0;
+        const int qy0 = min(max(py0, 0), g.Hf - 1) - ry0, qy1 = min(max(py0 + 1, 0), g.Hf - 1) - ry0;
+        float fx, fy;
+        if (__builtin_expect(qx0 >= 0 && qx1 < RW && qy0 >= 0 && qy1 < RH, 1)) {
+          const float2 a = u[qy0 * RW + qx0], b = u[qy0 * RW + qx1], c = u[qy1 * RW + qx0], d = u[qy1 * RW + qx1];
+          const float ax_ = (vy0 && vx0) ? a.x : 0.f, ay_ = (vy0 && vx0) ? a.y : 0.f;
+          const float bx_ = (vy0 && vx1) ? b.x : 0.f, by_ = (vy0 && vx1) ? b.y : 0.f;
+          const float cx_ = (vy1 && vx0) ? c.x : 0.f, cy_ = (vy1 && vx0) ? c.y : 0.f;
+          const float dx_ = (vy1 && vx1) ? d.x : 0.f, dy_ = (vy1 && vx1) ? d.y : 0.f;
+          const float nw = s * e, ne = s * w, sw = nn * e, se = nn * w;
+          fx = __builtin_fmaf(dx_, se, __builtin_fmaf(cx_, sw, __builtin_fmaf(bx_, ne, ax_ * nw)));
+          fy = __builtin_fmaf(dy_, se, __builtin_fmaf(cy_, sw, __builtin_fmaf(by_, ne, ay_ * nw)));
+        } else {
+          chain_step_generic(gx, g.h, g.w, cx[i], cy[i], fx, fy);
+        }
+        cx[i] = cx[i] + fx; cy[i] = cy[i] + fy;
+        sdx += cx[i] - x0f; sdy += cy[i] - (float)y; cnt += 1.f;
+      }
+    }
+    if (f + 1 < F1) {                       // where the chains are now, for the next region
+      sdx = wave_sum(sdx); sdy = wave_sum(sdy); cnt = wave_sum(cnt);
+      if (lane == 0) { red[wave][0] = sdx; red[wave][1] = sdy; red[wave][2] = cnt; }
+      __syncthreads();
+      float ax_ = 0.f, ay_ = 0.f, ac = 0.f;
+#pragma unroll
+      for (int k = 0; k < NWAVE; ++k) { ax_ += red[k][0]; ay_ += red[k][1]; ac += red[k][2]; }
+      const float mx = ac > 0.f ? ax_ / ac : 0.f, my = ac > 0.f ? ay_ / ac : 0.f;
+      // a performance hint only (any value gives the same results): keep it finite and bounded
+      shx = (int)rintf(fminf(fmaxf(mx, -4096.f), 4096.f));
+      shy = (int)rintf(fminf(fmaxf(my, -4096.f), 4096.f));
+    }
   }
-  float* p = out + (size_t)y * g.Wf + xb;
-  if (xb + PPX <= g.Wf && (g.Wf & 3) == 0) {
-    *reinterpret_cast<float4*>(p) = make_float4(ox[0], ox[1], ox[2], ox[3]);
-    *reinterpret_cast<float4*>(p + HW) = make_float4(oy[0], oy[1], oy[2], oy[3]);
-  } else {
-    for (int i = 0; i < PPX && xb + i < g.Wf; ++i) { p[i] = ox[i]; p[HW + i] = oy[i]; }
+#pragma unroll
+  for (int i = 0; i < CH_PX; ++i) {
+    const int y = ty0 + wave * CH_PX + i;
+    if (y < g.Hf && x < g.Wf) {
+      const size_t q = (size_t)y * g.Wf + x;
+      out[q] = cx[i] - x0f;
+      out[HW + q] = cy[i] - (float)y;
+    }
   }
 }
 
-// k_fbc_pair: both consistency masks of dense composed flows in one launch (direction in blockIdx.z & 1), 4 pixels
-// per thread, 16 B flow loads, exact constant division; the opposite flow is gathered from HBM/L2.
-__device__ __forceinline__ bool fbc_dense(float fx, float fy, const float* __restrict__ bx_, const float* __restrict__ by_,
-                                          const Up8Geom& g, float c0x, float c0y) {
-  const float fnx = div_c(2.f * fx, g.wd), fny = div_c(2.f * fy, g.ht);
-  const float c1x = c0x + fnx, c1y = c0y + fny;
-  if (!((fabsf(c1x) < 1.f) && (fabsf(c1y) < 1.f))) return false;
-  const float ix = (c1x + 1.f) * g.hx, iy = (c1y + 1.f) * g.hy;
-  const float xw = floorf(ix), yn = floorf(iy);
-  const float w = ix - xw, e = 1.f - w, n = iy - yn, s = 1.f - n;
-  const int x0 = (int)xw, y0 = (int)yn;
-  const int x1 = min(x0 + 1, g.Wf - 1), y1 = min(y0 + 1, g.Hf - 1);   // clamped taps carry weight 0 (see fbc_up8)
-  const unsigned o00 = y0 * g.Wf + x0, o01 = y0 * g.Wf + x1, o10 = y1 * g.Wf + x0, o11 = y1 * g.Wf + x1;
-  const float tx0 = div_c(2.f * bx_[o00], g.wd), tx1 = div_c(2.f * bx_[o01], g.wd), tx2 = div_c(2.f * bx_[o10], g.wd),
-              tx3 = div_c(2.f * bx_[o11], g.wd);
-  const float ty0 = div_c(2.f * by_[o00], g.ht), ty1 = div_c(2.f * by_[o01], g.ht), ty2 = div_c(2.f * by_[o10], g.ht),
-              ty3 = div_c(2.f * by_[o11], g.ht);
-  const float nw = s * e, ne = s * w, sw = n * e, se = n * w;
-  const float bx = __builtin_fmaf(tx3, se, __builtin_fmaf(tx2, sw, __builtin_fmaf(tx1, ne, tx0 * nw)));
-  const float by = __builtin_fmaf(ty3, se, __builtin_fmaf(ty2, sw, __builtin_fmaf(ty1, ne, ty0 * nw)));
-  const float cx = fnx + bx, cy = fny + by;
-  const float cyc = cx * cx + cy * cy;
-  const float eps = g.alpha1 * ((fnx * fnx + fny * fny) + (bx * bx + by * by)) + g.a2;
-  return (cyc - eps) <= 0.f;
+// k_fbc_pair: both consistency masks of dense composed flows in one launch (direction in blockIdx.z & 1).  The block
+// reads its tile of the own flow (coalesced), displaces the region by the tile's mean flow, stages the normalised
+// opposite flow over that region (coalesced row reads) and takes every tap from LDS.
+__device__ __attribute__((noinline)) bool fbc_dense_generic(const float* f, const float* o, int Hf, int Wf, int y, int x,
+                                                            float alpha1, float a2) {
+  const size_t HW = (size_t)Hf * Wf, r = (size_t)y * Wf + x;
+  float cx, cy;
+  return fbc_pixel(f[r], f[HW + r], FetchDense{o, o + HW, Wf}, Hf, Wf, y, x, alpha1, a2, 0, cx, cy);
 }
 
-__global__ void __launch_bounds__(PT_X* PT_Y)
+__global__ void __launch_bounds__(NT)
 k_fbc_pair(const float* __restrict__ flow_fwd, const float* __restrict__ flow_bwd, uint8_t* __restrict__ mask_fwd,
            uint8_t* __restrict__ mask_bwd, int32_t* __restrict__ invalid, int N, Up8Geom g) {
-  const int n = blockIdx.z >> 1, dir = blockIdx.z & 1;
+  __shared__ float2 no[RH * RW];           // normalised opposite flow over the region
+  __shared__ float red[NWAVE][3];
+  const int n = blockIdx.z >> 1, dir = blockIdx.z & 1, t = threadIdx.x;
   const size_t HW = (size_t)g.Hf * g.Wf;
   const float* f = (dir ? flow_bwd : flow_fwd) + (size_t)n * 2 * HW;
   const float* o = (dir ? flow_fwd : flow_bwd) + (size_t)n * 2 * HW;
   uint8_t* mask = (dir ? mask_bwd : mask_fwd) + (size_t)n * HW;
-  const int y = blockIdx.y * PT_Y + threadIdx.y;
-  const int xb = (blockIdx.x * PT_X + threadIdx.x) * PPX;
+  const int tx0 = blockIdx.x * TX, ty0 = blockIdx.y * TY;
+  const int wave = t >> 6, lane = t & 63;
+  const int x = tx0 + lane;
+  float2 fn[CH_PX];
+  float sdx = 0.f, sdy = 0.f, cnt = 0.f;
+#pragma unroll
+  for (int i = 0; i < CH_PX; ++i) {
+    const int y = ty0 + wave * CH_PX + i;
+    fn[i] = make_float2(0.f, 0.f);
+    if (y < g.Hf && x < g.Wf) {
+      const size_t q = (size_t)y * g.Wf + x;
+      const float fx = f[q], fy = f[HW + q];
+      fn[i] = make_float2(div_c(2.f * fx, g.wd), div_c(2.f * fy, g.ht));       // normalize_flow
+      sdx += fx; sdy += fy; cnt += 1.f;
+    }
+  }
+  sdx = wave_sum(sdx); sdy = wave_sum(sdy); cnt = wave_sum(cnt);
+  if (lane == 0) { red[wave][0] = sdx; red[wave][1] = sdy; red[wave][2] = cnt; }
+  __syncthreads();
+  float ax_ = 0.f, ay_ = 0.f, ac = 0.f;
+#pragma unroll
+  for (int k = 0; k < NWAVE; ++k) { ax_ += red[k][0]; ay_ += red[k][1]; ac += red[k][2]; }
+  const float mx = ac > 0.f ? ax_ / ac : 0.f, my = ac > 0.f ? ay_ / ac : 0.f;
+  const int shx = (int)rintf(fminf(fmaxf(mx, -4096.f), 4096.f)), shy = (int)rintf(fminf(fmaxf(my, -4096.f), 4096.f));
+  const int rx0 = min(max(tx0 - HL + shx, -HL), g.Wf - 1 - HL), ry0 = min(max(ty0 - HL + shy, -HL), g.Hf - 1 - HL);
+  for (int e = t; e < RH * RW; e += NT) {
+    const int r = e / RW, c = e - r * RW;
+    const size_t q = (size_t)min(max(ry0 + r, 0), g.Hf - 1) * g.Wf + min(max(rx0 + c, 0), g.Wf - 1);
+    no[e] = make_float2(div_c(2.f * o[q], g.wd), div_c(2.f * o[HW + q], g.ht));
+  }
+  __syncthreads();
+  const float c0x = div_c(2.f * (float)x, g.wd) - 1.f;
   int bad = 0;
-  if (y < g.Hf && xb < g.Wf) {
-    const size_t r = (size_t)y * g.Wf + xb;
-    const bool vec = xb + PPX <= g.Wf && (g.Wf & 3) == 0;
-    float fx[PPX], fy[PPX];
-    if (vec) {
-      const float4 a = *reinterpret_cast<const float4*>(f + r), b = *reinterpret_cast<const float4*>(f + HW + r);
-      fx[0] = a.x; fx[1] = a.y; fx[2] = a.z; fx[3] = a.w; fy[0] = b.x; fy[1] = b.y; fy[2] = b.z; fy[3] = b.w;
-    } else {
-      for (int i = 0; i < PPX; ++i) { const size_t q = (size_t)y * g.Wf + min(xb + i, g.Wf - 1); fx[i] = f[q]; fy[i] = f[HW + q]; }
-    }
-    const float c0y = div_c(2.f * (float)y, g.ht) - 1.f;
-    uint8_t m[PPX];
 #pragma unroll
-    for (int i = 0; i < PPX; ++i) {
-      const int x = min(xb + i, g.Wf - 1);
-      const float c0x = div_c(2.f * (float)x, g.wd) - 1.f;
-      m[i] = fbc_dense(fx[i], fy[i], o, o + HW, g, c0x, c0y) ? 1 : 0;
-      if (xb + i < g.Wf) bad += 1 - m[i];
+  for (int i = 0; i < CH_PX; ++i) {
+    const int y = ty0 + wave * CH_PX + i;
+    if (y >= g.Hf) break;
+    bool ok = true;
+    if (x < g.Wf) {
+      const float c0y = div_c(2.f * (float)y, g.ht) - 1.f;
+      bool slow = false;
+      ok = fbc_staged(fn[i], no, g, c0x, c0y, rx0, ry0, slow);
+      if (__builtin_expect(slow, 0)) ok = fbc_dense_generic(f, o, g.Hf, g.Wf, y, x, g.alpha1, g.a2);
+      mask[(size_t)y * g.Wf + x] = ok ? 1 : 0;
     }
-    if (vec) *reinterpret_cast<uchar4*>(mask + r) = make_uchar4(m[0], m[1], m[2], m[3]);
-    else for (int i = 0; i < PPX && xb + i < g.Wf; ++i) mask[r + i] = m[i];
+    bad += __popcll(__ballot(!ok));
   }
-  if (invalid) {
-#pragma unroll
-    for (int s = 32; s > 0; s >>= 1) bad += __shfl_xor(bad, s, 64);
-    if (threadIdx.x == 0 && bad) atomicAdd(&invalid[dir * N + n], bad);
-  }
+  if (invalid && lane == 0 && bad) atomicAdd(&invalid[dir * N + n], bad);
 }
 
 // ---- K8: calc_mask_ratio -----------------------------------------------------------------
@@ -563,8 +862,8 @@ int run_fbc(const float* f, const float* b, uint8_t* mask, float* cycle, int N, 
 static Up8Geom make_geom(int h, int w, int Hf, int Wf, float alpha1, float a2) {
   Up8Geom g;
   g.h = h; g.w = w; g.Hf = Hf; g.Wf = Wf;
-  g.sy = h > 1 ? (float)(h - 1) / (float)(8 * h - 1) : 0.f;
-  g.sx = w > 1 ? (float)(w - 1) / (float)(8 * w - 1) : 0.f;
+  g.sy = h > 1 ? (float)(h - 1) / (float)(Hf - 1) : 0.f;
+  g.sx = w > 1 ? (float)(w - 1) / (float)(Wf - 1) : 0.f;
   g.wd = make_divc((float)(Wf - 1)); g.ht = make_divc((float)(Hf - 1));
   g.hx = (float)(Wf - 1) / 2.f; g.hy = (float)(Hf - 1) / 2.f;
   g.alpha1 = alpha1; g.a2 = a2;
@@ -583,18 +882,26 @@ int run_flow_prepare(const float* lo_fwd, const float* lo_bwd, float* flow_fwd, 
       return PIXPRO_ERR_LAUNCH;
     }
   }
+  // the tiled kernels implement ATen's separable up-sampling (out_H + out_W > 128: every real frame size); the few
+  // smaller maps take the generic one-thread-per-pixel kernels, which know both forms
+  const dim3 grid((Wf + TX - 1) / TX, (Hf + TY - 1) / TY, 1);
+  const bool tiled = flow_up && up8_separable(h, w) && 2 * N <= 65535 && grid.y <= 65535;
   if (F1 == 1) {
-    if (flow_up && N <= 65535 && (Hf + PT_Y - 1) / PT_Y <= 65535) {
-      Up8Geom g;
-      g.h = h; g.w = w; g.Hf = Hf; g.Wf = Wf;
-      g.sy = h > 1 ? (float)(h - 1) / (float)(Hf - 1) : 0.f;
-      g.sx = w > 1 ? (float)(w - 1) / (float)(Wf - 1) : 0.f;
-      g.wd = make_divc((float)(Wf - 1)); g.ht = make_divc((float)(Hf - 1));
-      g.hx = (float)(Wf - 1) / 2.f; g.hy = (float)(Hf - 1) / 2.f;
-      g.alpha1 = alpha1; g.a2 = a2;
-      dim3 grid((Wf + PT_X * PPX - 1) / (PT_X * PPX), (Hf + PT_Y - 1) / PT_Y, N);
-      hipLaunchKernelGGL(k_prepare_up8, grid, dim3(PT_X, PT_Y), 0, st, lo_fwd, lo_bwd, flow_fwd, flow_bwd, mask_fwd,
-                         mask_bwd, invalid, N, g);
+    if (tiled) {
+      // PIXPRO_FLOW_PATH: auto (default) | certified (hand over only what the table cannot cover) | staged (hand over all):
+      // identical results, a knob for the tests and for timing the two paths
+      const char* path = getenv("PIXPRO_FLOW_PATH");
+      int force = !path ? 0 : !strcmp(path, "certified") ? 1 : !strcmp(path, "staged") ? 2 : 0;
+      if (!(alpha1 >= 0.f)) force = 2;      // the certificate needs eps >= a2, i.e. alpha1 >= 0
+      const Up8Geom g = make_geom(h, w, Hf, Wf, alpha1, a2);
+      hipLaunchKernelGGL(k_prepare_cert, dim3(grid.x, (Hf + TYC - 1) / TYC, N), dim3(NT_C), 0, st, lo_fwd, lo_bwd, flow_fwd, flow_bwd,
+                         mask_fwd, mask_bwd, invalid, N, g, force);
+      if (mask_fwd) {
+        CHECKED("k_prepare_cert");
+        const long ntiles = (long)grid.x * grid.y * N;
+        hipLaunchKernelGGL(k_prepare_staged, dim3((unsigned)(ntiles < 2048 ? ntiles : 2048)), dim3(NT), 0, st, lo_fwd,
+                           lo_bwd, mask_fwd, mask_bwd, invalid, N, g, (int)grid.x, (int)grid.y);
+      }
     } else if (flow_up) {
       Up8Source sf{lo_fwd, F1, h, w}, sb{lo_bwd, F1, h, w};
       hipLaunchKernelGGL(k_prepare_single<Up8Source>, dim3(blocks_for(n)), dim3(TPB), 0, st, sf, sb, flow_fwd,
@@ -604,18 +911,18 @@ int run_flow_prepare(const float* lo_fwd, const float* lo_bwd, float* flow_fwd, 
       hipLaunchKernelGGL(k_prepare_single<LoSource>, dim3(blocks_for(n)), dim3(TPB), 0, st, sf, sb, flow_fwd,
                          flow_bwd, mask_fwd, mask_bwd, invalid, N, Hf, Wf, alpha1, a2);
     }
-    CHECKED("k_prepare_single");
+    CHECKED("k_prepare");
     return PIXPRO_OK;
   }
-  // F-1 > 1: chains (up-sampling evaluated lazily, both directions in one launch), then both masks in one launch
-  const bool grid_ok = 2 * N <= 65535 && (Hf + PT_Y - 1) / PT_Y <= 65535;
-  if (grid_ok && flow_up && F1 <= CH_MAXF) {
+  // F-1 > 1: chains (both directions in one launch), then both masks in one launch
+  if (tiled) {
     const Up8Geom g = make_geom(h, w, Hf, Wf, alpha1, a2);
-    dim3 grid((Wf + PT_X * PPX - 1) / (PT_X * PPX), (Hf + PT_Y - 1) / PT_Y, 2 * N);
-    hipLaunchKernelGGL(k_chain_up8, grid, dim3(PT_X, PT_Y), 0, st, lo_fwd, lo_bwd, flow_fwd, flow_bwd, N, F1, g);
+    hipLaunchKernelGGL(k_chain_up8, dim3(grid.x, grid.y, 2 * N), dim3(NT), 0, st, lo_fwd, lo_bwd, flow_fwd, flow_bwd, N,
+                       F1, g);
     CHECKED("k_chain_up8");
     if (mask_fwd) {
-      hipLaunchKernelGGL(k_fbc_pair, grid, dim3(PT_X, PT_Y), 0, st, flow_fwd, flow_bwd, mask_fwd, mask_bwd, invalid, N, g);
+      hipLaunchKernelGGL(k_fbc_pair, dim3(grid.x, grid.y, 2 * N), dim3(NT), 0, st, flow_fwd, flow_bwd, mask_fwd,
+                         mask_bwd, invalid, N, g);
       CHECKED("k_fbc_pair");
     }
     return PIXPRO_OK;
@@ -631,12 +938,18 @@ int run_flow_prepare(const float* lo_fwd, const float* lo_bwd, float* flow_fwd, 
   }
   CHECKED("k_chain");
   if (mask_fwd) {
-    hipLaunchKernelGGL(k_fbc, dim3(blocks_for(n)), dim3(TPB), 0, st, flow_fwd, flow_bwd, mask_fwd, (float*)nullptr,
-                       invalid, N, Hf, Wf, alpha1, a2, 0);
-    CHECKED("k_fbc");
-    hipLaunchKernelGGL(k_fbc, dim3(blocks_for(n)), dim3(TPB), 0, st, flow_bwd, flow_fwd, mask_bwd, (float*)nullptr,
-                       invalid ? invalid + N : nullptr, N, Hf, Wf, alpha1, a2, 0);
-    CHECKED("k_fbc");
+    if (2 * N <= 65535 && grid.y <= 65535) {       // dense inputs: the tiled mask kernel does not up-sample anything
+      hipLaunchKernelGGL(k_fbc_pair, dim3(grid.x, grid.y, 2 * N), dim3(NT), 0, st, flow_fwd, flow_bwd, mask_fwd,
+                         mask_bwd, invalid, N, make_geom(h, w, Hf, Wf, alpha1, a2));
+      CHECKED("k_fbc_pair");
+    } else {
+      hipLaunchKernelGGL(k_fbc, dim3(blocks_for(n)), dim3(TPB), 0, st, flow_fwd, flow_bwd, mask_fwd, (float*)nullptr,
+                         invalid, N, Hf, Wf, alpha1, a2, 0);
+      CHECKED("k_fbc");
+      hipLaunchKernelGGL(k_fbc, dim3(blocks_for(n)), dim3(TPB), 0, st, flow_bwd, flow_fwd, mask_bwd, (float*)nullptr,
+                         invalid ? invalid + N : nullptr, N, Hf, Wf, alpha1, a2, 0);
+      CHECKED("k_fbc");
+    }
   }
   return PIXPRO_OK;
 }

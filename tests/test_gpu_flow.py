@@ -10,9 +10,11 @@ from gpu_utils import to_dev
 pytestmark = pytest.mark.gpu
 
 
-def test_upflow8_bitwise(dev):
+@pytest.mark.parametrize("tag", ["", "_big", "_edge128", "_edge136", "_edge136w"])
+def test_upflow8_bitwise(dev, tag):
+    """Both of ATen's CPU bilinear kernels (switch at output_H + output_W = 128) and the threshold itself."""
     from contrast import util
-    g = load_golden("upflow8")
+    g = load_golden("upflow8" + tag)
     out = util.upflow8(g["flow"].to(dev)).cpu()
     assert torch.equal(out, g["out"])
 
@@ -49,7 +51,7 @@ def _data(fw, bw, size, nfr, dev):
             [size.to(dev).repeat(N, 1), torch.full((N, 1), nfr, device=dev)]]
 
 
-@pytest.mark.parametrize("tag", ["f2up", "f6up", "f3noup"])
+@pytest.mark.parametrize("tag", ["f2up", "f6up", "f3noup", "f2up_big", "f6up_big", "f2up_bigmotion"])
 def test_apply_optical_flow_golden(dev, tag):
     from contrast import util
     g = load_golden(f"applyflow_{tag}")

@@ -135,8 +135,11 @@ def test_analytic_backward_general_p(p, clamp):
     assert torch.allclose(dx, xa.grad, atol=1e-10) and torch.allclose(dv, va.grad, atol=1e-10)
 
 
-def test_upflow8_bitwise():
-    g = load_golden("upflow8")
+@pytest.mark.parametrize("tag", ["", "_big", "_edge128", "_edge136", "_edge136w"])
+def test_upflow8_bitwise(tag):
+    """'' = 48x64 (ATen's small-output kernel); _big = 72x96, _edge136 = 72x64, _edge136w = 56x80 (the other kernel);
+    _edge128 = 64x64 sits exactly on the threshold output_H + output_W <= 128."""
+    g = load_golden("upflow8" + tag)
     assert torch.equal(O.upflow8(g["flow"]), g["out"])
 
 
@@ -165,7 +168,7 @@ def test_fbc_properties():
     assert torch.equal(O.concat_flow(z), torch.zeros(1, 2, 8, 8))
 
 
-@pytest.mark.parametrize("tag", ["f2up", "f6up", "f3noup"])
+@pytest.mark.parametrize("tag", ["f2up", "f6up", "f3noup", "f2up_big", "f6up_big", "f2up_bigmotion"])
 def test_apply_optical_flow_file(tag):
     g = load_golden(f"applyflow_{tag}")
     (f, s, mf), (b, _, mb) = O.apply_optical_flow_file(g["flow_fwds"], g["flow_bwds"], g["size"], bool(g["flow_up"]),
@@ -186,6 +189,31 @@ def test_lars_trajectory():
             wd = g["weight_decay"] if adapt else 0.0
             p[i], buf[i] = O.lars_sgd_step(p[i], g[f"g{s}_{i}"], buf[i], g["lr"], g["momentum"], wd, adapt)
             assert torch.allclose(p[i], g[f"p{s + 1}_{i}"], rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("hw", [(2, 2), (5, 7), (8, 8), (7, 9), (9, 7), (9, 8), (8, 9), (2, 14), (2, 15), (3, 21), (13, 5),
+                                (17, 29), (45, 80), (90, 160)])
+def test_aten_samplers_agree_on_upflow8_at_every_size(hw):
+    """The restated up-sampling against torch's own CPU kernels on both sides of the output_H + output_W = 128 switch
+    (h + w = 16), incl. the production size 90x160 -> 720x1280."""
+    lo = torch.randn(2, 2, *hw, generator=torch.Generator().manual_seed(hw[0] * 100 + hw[1]))
+    with O.aten_samplers():
+        ref = O.upflow8(lo)
+    assert torch.equal(O.upflow8(lo), ref)
+
+
+def test_aten_samplers_agree_production_size_chain():
+    """nframe = 3 at 720x1280 (chain + masks): explicit restatement == ATen kernels, bit for bit."""
+    from recipes import smooth_flow
+    gen = torch.Generator().manual_seed(3)
+    fw = smooth_flow((1, 2, 2, 90, 160), 0.5, gen)
+    bw = -fw.flip(1) + smooth_flow((1, 2, 2, 90, 160), 0.05, gen)
+    size = torch.tensor([720, 1280])
+    ref = O.apply_optical_flow_file(fw, bw, size, True, 0.01, 0.5)
+    with O.aten_samplers():
+        fast = O.apply_optical_flow_file(fw, bw, size, True, 0.01, 0.5)
+    for a, b in zip(ref, fast):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2])
 
 
 def test_aten_samplers_agree():
