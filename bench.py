@@ -511,17 +511,24 @@ def main():
         kernels = {}
         if "flow_prepare" in ms:
             t = ms["flow_prepare"] * 1e-3
-            kernels["flow_prepare"] = {"bound": "hbm", "achieved": round(b_flow * a.batch / t / 1e9, 1), "peak": HBM_PEAK / 1e9,
-                                       "unit": "GB/s", "frac": round(b_flow * a.batch / t / HBM_PEAK, 4),
+            # SURVEY 8d gives two per-image byte counts for the dense flow preparation: B_flow, what the reference's
+            # unfused pipeline moves (up-sampled maps written and read back), and the fused lower bound (read the
+            # 1/8-resolution maps once, write flows + masks once).  The launches here ARE fused, so the roofline is priced
+            # on the lower bound - what they must move; the B_flow ratio is kept beside it (it exceeds 1 for a fused
+            # kernel by construction and says nothing about kernel quality).
+            b_fused = (F1 * A / 16 + 4.5 * A)
+            kernels["flow_prepare"] = {"bound": "hbm", "achieved": round(b_fused * a.batch / t / 1e9, 1), "peak": HBM_PEAK / 1e9,
+                                       "unit": "GB/s", "frac": round(b_fused * a.batch / t / HBM_PEAK, 4),
                                        "traffic": pmc_traffic("flow_prepare", a)[0],
                                        "traffic_source": pmc_traffic("flow_prepare", a)[1],
                                        "ms_per_launch": round(ms["flow_prepare"], 4),
-                                       "algorithmic_bytes_per_launch": int(b_flow * a.batch),
-                                       "compulsory_bytes_per_launch": int((F1 * A / 16 + 4.5 * A) * a.batch),
-                                       "frac_compulsory": round((F1 * A / 16 + 4.5 * A) * a.batch / t / HBM_PEAK, 4),
-                                       "note": "algorithmic bytes = SURVEY 8d B_flow (reference's unfused dense pipeline); "
-                                               "the fused launch moves only the compulsory bytes and is VALU-bound "
-                                               "(bit-exact double bilinear), see DESIGN.md 4.3"}
+                                       "algorithmic_bytes_per_launch": int(b_fused * a.batch),
+                                       "unfused_pipeline_bytes_per_launch": int(b_flow * a.batch),
+                                       "ratio_to_unfused_pipeline_at_peak": round(b_flow * a.batch / t / HBM_PEAK, 4),
+                                       "note": "algorithmic bytes = SURVEY 8d fused lower bound ((F-1)A/16 + 4.5A per image: "
+                                               "low-res maps in, dense flows + masks out); SURVEY's B_flow prices the "
+                                               "reference's unfused pipeline and is reported as "
+                                               "ratio_to_unfused_pipeline_at_peak; DESIGN.md 4.3"}
         if "ppm_loss" in ms:
             t = ms["ppm_loss"] * 1e-3
             kernels["ppm_loss"] = {"bound": "mfma", "achieved": round(f_ppm * a.batch / t / 1e12, 3),

@@ -597,131 +597,121 @@ k_prepare_staged(const float* __restrict__ lo_fwd, const float* __restrict__ lo_
 }
 
 // ---- multi-frame (F-1 > 1): concat_flow over lazily up-sampled maps, both directions in one launch -----------------
-// One chain per pixel, advanced one flow at a time by the whole block: for flow t the block stages the up-sampled map
-// U_t (pixel units) over a region around where its chains currently ARE - the tile displaced by the block's mean drift
-// so far, so the halo only has to cover how much the drift varies inside a tile, not how large it is - and every chain
-// takes its four bilinear taps from LDS (zeros padding: taps outside the frame contribute 0, util.py:318-323).
-constexpr int CH_PX = TY / NWAVE;        // chains per thread: lane = x, CH_PX rows per wave
+// One chain per pixel; every step takes the four bilinear taps of U_t (the x8 up-sampling of flow t) at the chain's
+// current position straight from the flow's 1/8-resolution cells, which the block keeps in LDS for all flows of the
+// chain (tile + a margin that covers +-24 pixels of drift; positions beyond it read the cells from global memory).
+// No barrier after the load: chains are independent.  (A variant that staged U_t per step over a region following the
+// block's mean drift had the same instruction count and two barriers per step: 3.9 ms against 2.x at N = 64, F = 6.)
+constexpr int CH_MAXF = 6;                               // flows of a chain whose cell windows are kept in LDS
+constexpr int CMARG = 4;                                 // cells of margin around the cells under the tile
+constexpr int CWW = TX / 8 + 4 + 2 * CMARG, CWH = TYC / 8 + 4 + 2 * CMARG;   // 20 x 22 cells per flow
 
-__device__ __attribute__((noinline)) void chain_step_generic(const float* lo_t, int h, int w, float cx, float cy,
-                                                             float& fx, float& fy) {
-  const int Hf = 8 * h, Wf = 8 * w;
-  const FetchUp8 f{lo_t, lo_t + (size_t)h * w, h, w, up8_scale(h), up8_scale(w), up8_separable(h, w)};
-  bilinear2(f, Hf, Wf, 2.f * cx / (float)(Wf - 1) - 1.f, 2.f * cy / (float)(Hf - 1) - 1.f, TapNone(), fx, fy);
+struct ChainWin {
+  const float2* cells;     // this flow's LDS window
+  const float* gx;         // ... and its global planes, for positions outside the window
+  const float* gy;
+  int wx0, wy0, h, w;
+};
+// U_t from the 2 x 2 cells at `cell` of an LDS window
+__device__ __forceinline__ float2 up8_cell4(const float2* cell, const AxF& ay, const AxF& ax) {
+  const float2 a = cell[0], b = cell[1], c = cell[CWW], d = cell[CWW + 1];
+  return make_float2(8.f * up8_col(up8_row(a.x, b.x, ax.l0, ax.l1), up8_row(c.x, d.x, ax.l0, ax.l1), ay.l0, ay.l1),
+                     8.f * up8_col(up8_row(a.y, b.y, ax.l0, ax.l1), up8_row(c.y, d.y, ax.l0, ax.l1), ay.l0, ay.l1));
+}
+// U_t at pixel (ty, tx) inside the frame: separable x8 up-sampling of the four cells around it
+__device__ __forceinline__ float2 chain_tap(const ChainWin& cwn, const AxF& ay, const AxF& ax) {
+  const int ry = ay.i0 - cwn.wy0, rx = ax.i0 - cwn.wx0;
+  float2 a, b, c, d;
+  if (__builtin_expect((unsigned)ry < (unsigned)(CWH - 1) && (unsigned)rx < (unsigned)(CWW - 1), 1)) {
+    const float2* cell = cwn.cells + ry * CWW + rx;
+    a = cell[0]; b = cell[1]; c = cell[CWW]; d = cell[CWW + 1];
+  } else {
+    const int x1 = min(ax.i0 + 1, cwn.w - 1), y1 = min(ay.i0 + 1, cwn.h - 1);
+    const unsigned o00 = ay.i0 * cwn.w + ax.i0, o01 = ay.i0 * cwn.w + x1, o10 = y1 * cwn.w + ax.i0, o11 = y1 * cwn.w + x1;
+    a = make_float2(cwn.gx[o00], cwn.gy[o00]); b = make_float2(cwn.gx[o01], cwn.gy[o01]);
+    c = make_float2(cwn.gx[o10], cwn.gy[o10]); d = make_float2(cwn.gx[o11], cwn.gy[o11]);
+  }
+  return make_float2(8.f * up8_col(up8_row(a.x, b.x, ax.l0, ax.l1), up8_row(c.x, d.x, ax.l0, ax.l1), ay.l0, ay.l1),
+                     8.f * up8_col(up8_row(a.y, b.y, ax.l0, ax.l1), up8_row(c.y, d.y, ax.l0, ax.l1), ay.l0, ay.l1));
 }
 
-__global__ void __launch_bounds__(NT)
+__global__ void __launch_bounds__(NT_C)
 k_chain_up8(const float* __restrict__ lo_fwd, const float* __restrict__ lo_bwd, float* __restrict__ flow_fwd,
             float* __restrict__ flow_bwd, int N, int F1, Up8Geom g) {
-  __shared__ float2 u[RH * RW];            // U_t over the current region, pixel units
-  __shared__ float2 lw[LW_H * LW_W];       // low-res cells of flow t, replicate-padded
-  __shared__ float red[NWAVE][3];          // per-wave drift sums {dx, dy, count}
+  __shared__ float2 lwc[CH_MAXF][CWH * CWW];   // low-res cells of every flow under the tile + margin, replicate-padded
   const int n = blockIdx.z >> 1, dir = blockIdx.z & 1, t = threadIdx.x;
   const size_t hw = (size_t)g.h * g.w, HW = (size_t)g.Hf * g.Wf;
   const float* lo = (dir ? lo_bwd : lo_fwd) + (size_t)n * F1 * 2 * hw;          // [F1][2][h][w]
   float* out = (dir ? flow_bwd : flow_fwd) + (size_t)n * 2 * HW;
-  const int tx0 = blockIdx.x * TX, ty0 = blockIdx.y * TY;
-  const int wave = t >> 6, lane = t & 63;
+  const int tx0 = blockIdx.x * TX, ty0 = blockIdx.y * TYC;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
+  const int wx0 = axf(tx0, g.sx).i0 - CMARG, wy0 = axf(ty0, g.sy).i0 - CMARG;
+  for (int e = t; e < F1 * CWH * CWW; e += NT_C) {
+    const int f = e / (CWH * CWW), q = e - f * CWH * CWW, r = q / CWW, c = q - r * CWW;
+    const unsigned o = min(max(wy0 + r, 0), g.h - 1) * g.w + min(max(wx0 + c, 0), g.w - 1);
+    lwc[f][q] = make_float2(lo[(size_t)f * 2 * hw + o], lo[(size_t)f * 2 * hw + hw + o]);
+  }
+  __syncthreads();
   const int x = tx0 + lane;
+  if (x >= g.Wf) return;
   const float x0f = (float)x;
-  float cx[CH_PX], cy[CH_PX];
-#pragma unroll
-  for (int i = 0; i < CH_PX; ++i) { cx[i] = x0f; cy[i] = (float)(ty0 + wave * CH_PX + i); }
-  int shx = 0, shy = 0;                    // region displacement = rounded mean drift of the block's chains
-  int rc, r0;
-  stage_slot(t, rc, r0);
-  for (int f = 0; f < F1; ++f) {
-    const float* gx = lo + (size_t)f * 2 * hw;
-    const float* gy = gx + hw;
-    // keep the region on the frame: a region wholly outside it could serve no tap anyway
-    const int rx0 = min(max(tx0 - HL + shx, -HL), g.Wf - 1 - HL), ry0 = min(max(ty0 - HL + shy, -HL), g.Hf - 1 - HL);
-    const int wx0 = axf(max(rx0, 0), g.sx).i0, wy0 = axf(max(ry0, 0), g.sy).i0;
-    for (int e = t; e < LW_H * LW_W; e += NT) {
-      const int r = e / LW_W, c = e - r * LW_W;
-      const unsigned o = min(wy0 + r, g.h - 1) * g.w + min(wx0 + c, g.w - 1);
-      lw[e] = make_float2(gx[o], gy[o]);
-    }
-    __syncthreads();
-    {
-      const AxF ax = axf(min(max(rx0 + rc, 0), g.Wf - 1), g.sx);
-      const int cxi = ax.i0 - wx0;
-      float2 t0 = make_float2(0.f, 0.f), t1 = t0;
-      int have = -2;
 #pragma unroll 2
-      for (int r = r0; r < r0 + ROWS_PER_GROUP; ++r) {
-        const AxF ay = axf(min(max(ry0 + r, 0), g.Hf - 1), g.sy);
-        if (ay.i0 != have) {
-          const float2* cell = lw + (ay.i0 - wy0) * LW_W + cxi;
-          if (ay.i0 == have + 1) {
-            t0 = t1;
-          } else {
-            const float2 a = cell[0], b = cell[1];
-            t0 = make_float2(up8_row(a.x, b.x, ax.l0, ax.l1), up8_row(a.y, b.y, ax.l0, ax.l1));
-          }
-          const float2 c = cell[LW_W], d = cell[LW_W + 1];
-          t1 = make_float2(up8_row(c.x, d.x, ax.l0, ax.l1), up8_row(c.y, d.y, ax.l0, ax.l1));
-          have = ay.i0;
+  for (int i = 0; i < ROWS_C; ++i) {
+    const int y = ty0 + wave * ROWS_C + i;
+    if (y >= g.Hf) break;
+    float cx = x0f, cy = (float)y;
+    for (int f = 0; f < F1; ++f) {
+      const ChainWin cwn{lwc[f], lo + (size_t)f * 2 * hw, lo + (size_t)f * 2 * hw + hw, wx0, wy0, g.h, g.w};
+      const float nx = div_c(2.f * cx, g.wd) - 1.f, ny = div_c(2.f * cy, g.ht) - 1.f;   // normalize_coord
+      const float ix = (nx + 1.f) * g.hx, iy = (ny + 1.f) * g.hy;
+      const float xw = floorf(ix), yn = floorf(iy);
+      const float w = ix - xw, e = 1.f - w, nn = iy - yn, s = 1.f - nn;
+      const float nw = s * e, ne = s * w, sw = nn * e, se = nn * w;
+      float fx, fy;
+      if (__builtin_expect(xw >= 0.f && xw < (float)(g.Wf - 1) && yn >= 0.f && yn < (float)(g.Hf - 1), 1)) {
+        // all four taps inside the frame (the usual case): no padding logic, one window test for the 2 x 2 block of taps
+        const int px0 = (int)xw, py0 = (int)yn;
+        const AxF ax0 = axf(px0, g.sx), ax1 = axf(px0 + 1, g.sx), ay0 = axf(py0, g.sy), ay1 = axf(py0 + 1, g.sy);
+        const int rx = ax0.i0 - wx0, ry = ay0.i0 - wy0;
+        float2 a, b, c, d;
+        if (__builtin_expect((unsigned)rx < (unsigned)(CWW - 2) && (unsigned)ry < (unsigned)(CWH - 2), 1)) {
+          // ax1.i0 - ax0.i0 and ay1.i0 - ay0.i0 are 0 or 1: every cell below lies inside the window
+          const float2* c00 = cwn.cells + ry * CWW + rx;
+          const float2* c01 = c00 + (ax1.i0 - ax0.i0);
+          const int dy = (ay1.i0 - ay0.i0) * CWW;
+          a = up8_cell4(c00, ay0, ax0); b = up8_cell4(c01, ay0, ax1);
+          c = up8_cell4(c00 + dy, ay1, ax0); d = up8_cell4(c01 + dy, ay1, ax1);
+        } else {
+          a = chain_tap(cwn, ay0, ax0); b = chain_tap(cwn, ay0, ax1); c = chain_tap(cwn, ay1, ax0); d = chain_tap(cwn, ay1, ax1);
         }
-        u[r * RW + rc] = make_float2(8.f * up8_col(t0.x, t1.x, ay.l0, ay.l1), 8.f * up8_col(t0.y, t1.y, ay.l0, ay.l1));
-      }
-    }
-    __syncthreads();
-    float sdx = 0.f, sdy = 0.f, cnt = 0.f;
-#pragma unroll
-    for (int i = 0; i < CH_PX; ++i) {
-      const int y = ty0 + wave * CH_PX + i;
-      if (y < g.Hf && x < g.Wf) {
-        const float nx = div_c(2.f * cx[i], g.wd) - 1.f, ny = div_c(2.f * cy[i], g.ht) - 1.f;   // normalize_coord
-        const float ix = (nx + 1.f) * g.hx, iy = (ny + 1.f) * g.hy;
-        const float xw = floorf(ix), yn = floorf(iy);
-        const float w = ix - xw, e = 1.f - w, nn = iy - yn, s = 1.f - nn;
+        fx = __builtin_fmaf(d.x, se, __builtin_fmaf(c.x, sw, __builtin_fmaf(b.x, ne, a.x * nw)));
+        fy = __builtin_fmaf(d.y, se, __builtin_fmaf(c.y, sw, __builtin_fmaf(b.y, ne, a.y * nw)));
+      } else {
+        // float -> int keeping far-away (or NaN) coordinates out of range; taps outside the frame contribute zero
         const int px0 = (xw > -2.f && xw < (float)(g.Wf + 1)) ? (int)xw : -2;
         const int py0 = (yn > -2.f && yn < (float)(g.Hf + 1)) ? (int)yn : -2;
         const bool vx0 = px0 >= 0 && px0 < g.Wf, vx1 = px0 + 1 >= 0 && px0 + 1 < g.Wf;
         const bool vy0 = py0 >= 0 && py0 < g.Hf, vy1 = py0 + 1 >= 0 && py0 + 1 < g.Hf;
-        // region coordinates of the taps that count (clamped to the frame: a clamped tap outside it is discarded)
-        const int qx0 = min(max(px0, 0), g.Wf - 1) - rx0, qx1 = min(max(px0 + 1, 0), g.Wf - 1) - rx0;
-        const int qy0 = min(max(py0, 0), g.Hf - 1) - ry0, qy1 = min(max(py0 + 1, 0), g.Hf - 1) - ry0;
-        float fx, fy;
-        if (__builtin_expect(qx0 >= 0 && qx1 < RW && qy0 >= 0 && qy1 < RH, 1)) {
-          const float2 a = u[qy0 * RW + qx0], b = u[qy0 * RW + qx1], c = u[qy1 * RW + qx0], d = u[qy1 * RW + qx1];
-          const float ax_ = (vy0 && vx0) ? a.x : 0.f, ay_ = (vy0 && vx0) ? a.y : 0.f;
-          const float bx_ = (vy0 && vx1) ? b.x : 0.f, by_ = (vy0 && vx1) ? b.y : 0.f;
-          const float cx_ = (vy1 && vx0) ? c.x : 0.f, cy_ = (vy1 && vx0) ? c.y : 0.f;
-          const float dx_ = (vy1 && vx1) ? d.x : 0.f, dy_ = (vy1 && vx1) ? d.y : 0.f;
-          const float nw = s * e, ne = s * w, sw = nn * e, se = nn * w;
-          fx = __builtin_fmaf(dx_, se, __builtin_fmaf(cx_, sw, __builtin_fmaf(bx_, ne, ax_ * nw)));
-          fy = __builtin_fmaf(dy_, se, __builtin_fmaf(cy_, sw, __builtin_fmaf(by_, ne, ay_ * nw)));
-        } else {
-          chain_step_generic(gx, g.h, g.w, cx[i], cy[i], fx, fy);
-        }
-        cx[i] = cx[i] + fx; cy[i] = cy[i] + fy;
-        sdx += cx[i] - x0f; sdy += cy[i] - (float)y; cnt += 1.f;
+        const AxF ax0 = axf(min(max(px0, 0), g.Wf - 1), g.sx), ax1 = axf(min(max(px0 + 1, 0), g.Wf - 1), g.sx);
+        const AxF ay0 = axf(min(max(py0, 0), g.Hf - 1), g.sy), ay1 = axf(min(max(py0 + 1, 0), g.Hf - 1), g.sy);
+        float2 a = chain_tap(cwn, ay0, ax0), b = chain_tap(cwn, ay0, ax1), c = chain_tap(cwn, ay1, ax0),
+               d = chain_tap(cwn, ay1, ax1);
+        if (!(vy0 && vx0)) a = make_float2(0.f, 0.f);
+        if (!(vy0 && vx1)) b = make_float2(0.f, 0.f);
+        if (!(vy1 && vx0)) c = make_float2(0.f, 0.f);
+        if (!(vy1 && vx1)) d = make_float2(0.f, 0.f);
+        fx = __builtin_fmaf(d.x, se, __builtin_fmaf(c.x, sw, __builtin_fmaf(b.x, ne, a.x * nw)));
+        fy = __builtin_fmaf(d.y, se, __builtin_fmaf(c.y, sw, __builtin_fmaf(b.y, ne, a.y * nw)));
       }
+      cx = cx + fx; cy = cy + fy;
     }
-    if (f + 1 < F1) {                       // where the chains are now, for the next region
-      sdx = wave_sum(sdx); sdy = wave_sum(sdy); cnt = wave_sum(cnt);
-      if (lane == 0) { red[wave][0] = sdx; red[wave][1] = sdy; red[wave][2] = cnt; }
-      __syncthreads();
-      float ax_ = 0.f, ay_ = 0.f, ac = 0.f;
-#pragma unroll
-      for (int k = 0; k < NWAVE; ++k) { ax_ += red[k][0]; ay_ += red[k][1]; ac += red[k][2]; }
-      const float mx = ac > 0.f ? ax_ / ac : 0.f, my = ac > 0.f ? ay_ / ac : 0.f;
-      // a performance hint only (any value gives the same results): keep it finite and bounded
-      shx = (int)rintf(fminf(fmaxf(mx, -4096.f), 4096.f));
-      shy = (int)rintf(fminf(fmaxf(my, -4096.f), 4096.f));
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < CH_PX; ++i) {
-    const int y = ty0 + wave * CH_PX + i;
-    if (y < g.Hf && x < g.Wf) {
-      const size_t q = (size_t)y * g.Wf + x;
-      out[q] = cx[i] - x0f;
-      out[HW + q] = cy[i] - (float)y;
-    }
+    const size_t q = (size_t)y * g.Wf + x;
+    out[q] = cx - x0f;
+    out[HW + q] = cy - (float)y;
   }
 }
+
+constexpr int CH_PX = TY / NWAVE;        // pixels per thread of the mask kernel: lane = x, CH_PX rows per wave
 
 // k_fbc_pair: both consistency masks of dense composed flows in one launch (direction in blockIdx.z & 1).  The block
 // reads its tile of the own flow (coalesced), displaces the region by the tile's mean flow, stages the normalised
@@ -915,10 +905,10 @@ int run_flow_prepare(const float* lo_fwd, const float* lo_bwd, float* flow_fwd, 
     return PIXPRO_OK;
   }
   // F-1 > 1: chains (both directions in one launch), then both masks in one launch
-  if (tiled) {
+  if (tiled && F1 <= CH_MAXF) {
     const Up8Geom g = make_geom(h, w, Hf, Wf, alpha1, a2);
-    hipLaunchKernelGGL(k_chain_up8, dim3(grid.x, grid.y, 2 * N), dim3(NT), 0, st, lo_fwd, lo_bwd, flow_fwd, flow_bwd, N,
-                       F1, g);
+    hipLaunchKernelGGL(k_chain_up8, dim3(grid.x, (Hf + TYC - 1) / TYC, 2 * N), dim3(NT_C), 0, st, lo_fwd, lo_bwd, flow_fwd,
+                       flow_bwd, N, F1, g);
     CHECKED("k_chain_up8");
     if (mask_fwd) {
       hipLaunchKernelGGL(k_fbc_pair, dim3(grid.x, grid.y, 2 * N), dim3(NT), 0, st, flow_fwd, flow_bwd, mask_fwd,
