@@ -86,6 +86,9 @@ def parse():
                          "with several: every SyncBN collective of a process goes through ProcessGroupNCCL's one internal stream "
                          "in host order, so with >1 rank the two branches would serialise at every layer anyway")
     ap.add_argument("--no-overlap-momentum", dest="overlap_momentum", action="store_const", const="off")
+    ap.add_argument("--bn-view-batch", action="store_true",
+                    help="both views of an encoder in one pass with per-view BatchNorm statistics: half the SyncBN collectives "
+                         "(same statistics); unmeasured on more than one GPU, off by default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dry-launch", action="store_true",
                     help="launcher check without a GPU: start the ranks, form the process group over gloo on the CPU, run the "
@@ -115,6 +118,8 @@ def model_args(a, world):
         argv.append("--lazy-flow")
     if a.fused_bn:
         argv.append("--fused-bn")
+    if a.bn_view_batch:
+        argv.append("--bn-view-batch")
     a.overlap_momentum = a.overlap_momentum == "on" or (a.overlap_momentum == "auto" and world == 1)
     if a.overlap_momentum:
         argv.append("--overlap-momentum")
@@ -588,7 +593,8 @@ def main():
             "config": {"workload": f"{a.arch} PixPro+optical-flow pre-train step, {a.image_size}x{a.image_size} crops, "
                                    f"nframe={a.n_frames}, 720x1280 frames, file-mode flow (flow_up, alpha1=0.01, alpha2=0.5), "
                                    f"p=2, transform_layer=1, LARS, fp32",
-                       "batch_norm": "fused HIP SyncBN+ReLU" if a.fused_bn else "torch (Sync)BatchNorm",
+                       "batch_norm": ("fused HIP SyncBN+ReLU" + (", two views per pass" if a.bn_view_batch else ""))
+                                     if a.fused_bn else "torch (Sync)BatchNorm",
                        "key_branch": "second HIP stream" if a.overlap_momentum else "same stream",
                        "miopen": f"immediate mode; {miopen_note}",
                        "flow_mode": "lazy (flow + mask evaluated at the loss sample points)" if a.lazy_flow else "dense",

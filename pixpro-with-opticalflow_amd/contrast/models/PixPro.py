@@ -25,7 +25,7 @@ from torch.distributed import get_world_size, is_initialized
 
 from .. import ops
 from ..multi_tensor import ema_update
-from ..sync_bn import FusedSyncBatchNorm, bn_act
+from ..sync_bn import FusedSyncBatchNorm, bn_act, view_groups
 from .base import BaseModel
 
 
@@ -105,6 +105,11 @@ class PixPro(BaseModel):
         self.pixpro_ins_loss_weight = args.pixpro_ins_loss_weight
         self.output_root = getattr(args, "output_dir", None)
         self.overlap_momentum = bool(getattr(args, "overlap_momentum", False))
+        # both views of an encoder in one pass, BatchNorm statistics still per view (sync_bn.view_groups): the per-layer
+        # SyncBN collectives of the two views travel together, 162 instead of 324 per step
+        self.view_batch = bool(getattr(args, "bn_view_batch", False))
+        if self.view_batch and not getattr(args, "fused_bn", False):
+            raise ValueError("--bn-view-batch needs --fused-bn: stock BatchNorm would pool the statistics of the two views")
         self._side_stream = None
 
         self.encoder = base_encoder(head_type="early_return")
@@ -184,10 +189,28 @@ class PixPro(BaseModel):
     def regression_loss(self, x, y):
         return -2. * torch.einsum('nc, nc->n', [x, y]).mean()
 
+    def _two_views(self, encoder, projector, im_1, im_2):
+        """(feat_1, proj_1, feat_2, proj_2) of one encoder + projector: two passes as in the reference (PixPro.py:376-384),
+        or one pass over both views with per-view BatchNorm statistics."""
+        if self.view_batch:
+            with view_groups(2):
+                feat = encoder(torch.cat([im_1, im_2]))
+                proj = projector(feat)
+            (feat_1, feat_2), (proj_1, proj_2) = feat.chunk(2), proj.chunk(2)
+            return feat_1, proj_1, feat_2, proj_2
+        feat_1 = encoder(im_1)
+        proj_1 = projector(feat_1)
+        feat_2 = encoder(im_2)
+        proj_2 = projector(feat_2)
+        return feat_1, proj_1, feat_2, proj_2
+
     def _momentum_passes(self, im_1, im_2, is_update_momentum):
         with torch.no_grad():
             if is_update_momentum:
                 self._momentum_update_key_encoder()
+            if self.view_batch:
+                feat_1_ng, key_1, feat_2_ng, key_2 = self._two_views(self.encoder_k, self.projector_k, im_1, im_2)
+                return key_1, key_2, feat_1_ng, feat_2_ng
             feat_1_ng = self.encoder_k(im_1)
             key_1 = self.projector_k(feat_1_ng)          # normalised inside the kernel (:403)
             feat_2_ng = self.encoder_k(im_2)
@@ -209,10 +232,7 @@ class PixPro(BaseModel):
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 key_1, key_2, feat_1_ng, feat_2_ng = self._momentum_passes(im_1, im_2, is_update_momentum)
-        feat_1 = self.encoder(im_1)
-        proj_1 = self.projector(feat_1)
-        feat_2 = self.encoder(im_2)
-        proj_2 = self.projector(feat_2)
+        feat_1, proj_1, feat_2, proj_2 = self._two_views(self.encoder, self.projector, im_1, im_2)
         val_1 = self.value_transform(proj_1)
         val_2 = self.value_transform(proj_2)
         if overlap:

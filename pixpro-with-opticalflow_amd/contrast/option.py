@@ -89,6 +89,9 @@ _FLAGS = [
                                                              "concurrently with the online branch")),
     (("--fused-bn",), dict(action="store_true", help="HIP (Sync)BatchNorm with the ReLU / residual add folded in "
                                                      "(needs --channels-last)")),
+    (("--bn-view-batch",), dict(action="store_true", help="run both views through an encoder in ONE pass with per-view "
+                                                          "BatchNorm statistics (needs --fused-bn): same statistics, half "
+                                                          "the SyncBN collectives per step")),
 ]
 
 

@@ -45,9 +45,41 @@ def _world(group):
     return dist.get_world_size(group)
 
 
+_VIEW_GROUPS = 1
+
+
+class view_groups:
+    """`with view_groups(2): encoder(torch.cat([im_1, im_2]))` - the batch holds G views of N samples each (view g =
+    samples [g*N, (g+1)*N)) and every FusedSyncBatchNorm inside normalises each view with ITS OWN statistics, exactly as
+    G separate forward passes would (same kernels on the same rows, running statistics updated view after view), but
+    the G per-view records of a layer cross the process group in ONE collective per direction: all_gather of
+    [G, 2C+1] floats forward, all_reduce of [G, 2C] floats backward.  PixPro runs two views through each encoder
+    (contrast/models/PixPro.py:376-407), so this halves the 324 SyncBN collectives of a step without
+    changing a statistic."""
+
+    def __init__(self, groups):
+        self.groups = int(groups)
+
+    def __enter__(self):
+        global _VIEW_GROUPS
+        self.prev, _VIEW_GROUPS = _VIEW_GROUPS, self.groups
+
+    def __exit__(self, *exc):
+        global _VIEW_GROUPS
+        _VIEW_GROUPS = self.prev
+
+
+def _part(t, g, G):
+    """View g of G along the batch dimension (a contiguous block of rows in channels_last / row-major storage)."""
+    if t is None or G == 1:
+        return t
+    n = t.shape[0] // G
+    return t.narrow(0, g * n, n)
+
+
 class _FusedBN(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, running_mean, running_var, momentum, eps, relu, group):
+    def forward(ctx, x, weight, bias, residual, running_mean, running_var, momentum, eps, relu, group, G):
         x, rows, C = _rows_view(x, "input")
         if not x.is_cuda or x.dtype != torch.float32:
             raise RuntimeError("FusedSyncBatchNorm runs on fp32 GPU tensors only; there is no CPU fallback")
@@ -55,67 +87,85 @@ class _FusedBN(torch.autograd.Function):
             residual, r_rows, r_C = _rows_view(residual, "residual")
             if (r_rows, r_C) != (rows, C):
                 raise RuntimeError(f"residual shape {tuple(residual.shape)} does not match input {tuple(x.shape)}")
+        if x.shape[0] % G:
+            raise RuntimeError(f"view_groups({G}): batch {x.shape[0]} is not a multiple of the number of views")
+        rows //= G
         dev = x.device
         f32 = dict(dtype=torch.float32, device=dev)
         wsb = nv.load().pixpro_bn_workspace_bytes(rows, C)
         if wsb == 0:
             raise RuntimeError(f"FusedSyncBatchNorm: unsupported shape rows={rows}, C={C} (C must be a multiple of 4)")
         ws = nv.workspace(wsb, dev)
-        packed = torch.empty(2 * C + 1, **f32)
-        nv.call("pixpro_bn_stats", nv.ptr(x), rows, C, nv.ptr(ws), wsb, nv.ptr(packed), nv.stream())
+        packed = torch.empty(G, 2 * C + 1, **f32)
+        for g in range(G):
+            nv.call("pixpro_bn_stats", nv.ptr(_part(x, g, G)), rows, C, nv.ptr(ws), wsb, nv.ptr(packed[g]), nv.stream())
         world = _world(group)
         if world > 1:
-            gathered = torch.empty(world, 2 * C + 1, **f32)
+            gathered = torch.empty(world, G, 2 * C + 1, **f32)
             if dist.get_backend(group) == "gloo":      # rehearsal / tests: no all_gather_into_tensor on gloo
                 parts = list(gathered.unbind(0))
                 dist.all_gather(parts, packed, group=group)
                 gathered = torch.stack(parts)
             else:
                 dist.all_gather_into_tensor(gathered, packed, group=group)
+            # the kernels read one view's records as [world, 2C+1]
+            gathered = gathered.transpose(0, 1).contiguous() if G > 1 else gathered.reshape(1, world, 2 * C + 1)
         else:
-            gathered = packed
+            gathered = packed.reshape(G, 1, 2 * C + 1)
         y = torch.empty_like(x)
-        mean, invstd, scale_shift = torch.empty(C, **f32), torch.empty(C, **f32), torch.empty(2 * C, **f32)
-        nv.call("pixpro_bn_apply", nv.ptr(gathered), world, nv.ptr(x), nv.ptr(residual), nv.ptr(weight), nv.ptr(bias),
-                nv.ptr(running_mean), nv.ptr(running_var), float(momentum), float(eps), int(relu), rows, C, nv.ptr(y),
-                nv.ptr(mean), nv.ptr(invstd), nv.ptr(scale_shift), nv.stream())
+        mean, invstd, scale_shift = torch.empty(G, C, **f32), torch.empty(G, C, **f32), torch.empty(G, 2 * C, **f32)
+        for g in range(G):         # view after view: the running statistics see the same sequence of updates as G passes
+            nv.call("pixpro_bn_apply", nv.ptr(gathered[g]), world, nv.ptr(_part(x, g, G)), nv.ptr(_part(residual, g, G)),
+                    nv.ptr(weight), nv.ptr(bias), nv.ptr(running_mean), nv.ptr(running_var), float(momentum), float(eps),
+                    int(relu), rows, C, nv.ptr(_part(y, g, G)), nv.ptr(mean[g]), nv.ptr(invstd[g]), nv.ptr(scale_shift[g]),
+                    nv.stream())
         # the ReLU decision is recomputed from x in backward unless a residual entered it (then the output is needed)
         ctx.save_for_backward(x, y if (relu and residual is not None) else None, weight, mean, invstd,
                               scale_shift if (relu and residual is None) else None, gathered)
-        ctx.meta = (rows, C, bool(relu), residual is not None, group, world)
+        ctx.meta = (rows, C, bool(relu), residual is not None, group, world, G)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, y, weight, mean, invstd, scale_shift, gathered = ctx.saved_tensors
-        rows, C, relu, has_res, group, world = ctx.meta
+        rows, C, relu, has_res, group, world, G = ctx.meta
         if dy.dim() == 4 and not dy.is_contiguous(memory_format=torch.channels_last) or dy.dim() == 2 and not dy.is_contiguous():
             dy = dy.contiguous(memory_format=torch.channels_last) if dy.dim() == 4 else dy.contiguous()
         dev = x.device
         f32 = dict(dtype=torch.float32, device=dev)
         wsb = nv.load().pixpro_bn_workspace_bytes(rows, C)
         ws = nv.workspace(wsb, dev)
-        sums = torch.empty(2 * C, **f32)
+        sums = torch.empty(G, 2 * C, **f32)
         need_w = weight is not None and ctx.needs_input_grad[1]
         need_b = ctx.needs_input_grad[2]
-        gw = torch.empty(C, **f32) if need_w else None
-        gb = torch.empty(C, **f32) if need_b else None
-        nv.call("pixpro_bn_backward_reduce", nv.ptr(dy), nv.ptr(x), nv.ptr(y), nv.ptr(scale_shift), nv.ptr(mean),
-                nv.ptr(invstd), int(relu),
-                rows, C, nv.ptr(ws), wsb, nv.ptr(sums), nv.ptr(gw), nv.ptr(gb), nv.stream())
+        gw = torch.empty(G, C, **f32) if need_w else None
+        gb = torch.empty(G, C, **f32) if need_b else None
+        for g in range(G):
+            nv.call("pixpro_bn_backward_reduce", nv.ptr(_part(dy, g, G)), nv.ptr(_part(x, g, G)), nv.ptr(_part(y, g, G)),
+                    nv.ptr(scale_shift[g] if scale_shift is not None else None), nv.ptr(mean[g]), nv.ptr(invstd[g]),
+                    int(relu), rows, C, nv.ptr(ws), wsb, nv.ptr(sums[g]), nv.ptr(gw[g] if need_w else None),
+                    nv.ptr(gb[g] if need_b else None), nv.stream())
         if world > 1:
-            dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+            dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)     # ONE collective for all views of the layer
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         dres = torch.empty_like(x) if (has_res and ctx.needs_input_grad[3]) else None
         if dx is None and dres is not None:
             dx = torch.empty_like(x)
         if dx is not None:
-            # the total row count is the sum of what the ranks exchanged in forward (element 2C of each packed record)
-            counts = ctypes.c_void_p(gathered.data_ptr() + 2 * C * 4)
-            nv.call("pixpro_bn_backward_apply", nv.ptr(dy), nv.ptr(x), nv.ptr(y), nv.ptr(scale_shift), nv.ptr(mean),
-                    nv.ptr(invstd), nv.ptr(weight), nv.ptr(sums), counts, world, 2 * C + 1, int(relu), rows, C,
-                    nv.ptr(dx), nv.ptr(dres), nv.stream())
-        return dx, gw, gb, dres, None, None, None, None, None, None
+            for g in range(G):
+                # the total row count is the sum of what the ranks exchanged in forward (element 2C of each packed record)
+                counts = ctypes.c_void_p(gathered[g].data_ptr() + 2 * C * 4)
+                nv.call("pixpro_bn_backward_apply", nv.ptr(_part(dy, g, G)), nv.ptr(_part(x, g, G)), nv.ptr(_part(y, g, G)),
+                        nv.ptr(scale_shift[g] if scale_shift is not None else None), nv.ptr(mean[g]), nv.ptr(invstd[g]),
+                        nv.ptr(weight), nv.ptr(sums[g]), counts, world, 2 * C + 1, int(relu), rows, C,
+                        nv.ptr(_part(dx, g, G)), nv.ptr(_part(dres, g, G)), nv.stream())
+        if G > 1:                # the views' contributions in pass order, as autograd would accumulate them
+            gw = gw.sum(0) if need_w else None
+            gb = gb.sum(0) if need_b else None
+        else:
+            gw = gw[0] if need_w else None
+            gb = gb[0] if need_b else None
+        return dx, gw, gb, dres, None, None, None, None, None, None, None
 
 
 class FusedSyncBatchNorm(nn.modules.batchnorm._BatchNorm):
@@ -137,11 +187,11 @@ class FusedSyncBatchNorm(nn.modules.batchnorm._BatchNorm):
         self._check_input_dim(input)
         if self.training or not self.track_running_stats:
             if self.training and self.track_running_stats and self.num_batches_tracked is not None:
-                self.num_batches_tracked.add_(1)
+                self.num_batches_tracked.add_(_VIEW_GROUPS)
             rm = self.running_mean if (self.training and self.track_running_stats) else None
             rv = self.running_var if (self.training and self.track_running_stats) else None
             return _FusedBN.apply(input, self.weight, self.bias, residual, rm, rv, self.momentum, self.eps, relu,
-                                  self.process_group)
+                                  self.process_group, _VIEW_GROUPS)
         out = F.batch_norm(input, self.running_mean, self.running_var, self.weight, self.bias, False, 0.0, self.eps)
         if residual is not None:
             out = out + residual

@@ -196,3 +196,139 @@ def test_model_step_with_fused_bn_matches_stock(dev):
     close(out[1][3], out[0][3], rel=2e-3)
     close(out[1][2], out[0][2], rel=3e-2)       # 53 normalisations deep; re-association noise amplified by BN at 32 values
     assert torch.allclose(out[0][4], out[1][4], rtol=1e-4)
+
+
+@pytest.mark.parametrize("relu,with_res", [(True, False), (True, True), (False, False)])
+def test_view_groups_equal_two_separate_passes(dev, relu, with_res):
+    """view_groups(2): one call over [view 1; view 2] == two calls, bit for bit - outputs, every gradient, and the running
+    statistics after the two sequential updates (the reference makes two passes, PixPro.py:376-384)."""
+    from contrast.sync_bn import FusedSyncBatchNorm, view_groups
+    g = torch.Generator().manual_seed(5 + relu + 2 * with_res)
+    N, C, H, W = 6, 64, 9, 7
+
+    def mk():
+        return [(torch.randn(N, C, H, W, generator=g) * s + m).to(dev).contiguous(memory_format=CL) for s, m in ((1.5, 0.3), (0.7, -1.0))]
+    xs, rs, dys = mk(), mk(), mk()
+    out = []
+    for batched in (False, True):
+        bn = FusedSyncBatchNorm(C).to(dev).train()
+        with torch.no_grad():
+            bn.weight.copy_(torch.linspace(0.5, 1.5, C)); bn.bias.copy_(torch.linspace(-0.3, 0.3, C))
+        xa = [x.clone().requires_grad_(True) for x in xs]
+        ra = [r.clone().requires_grad_(True) for r in rs] if with_res else [None, None]
+        if batched:
+            x2 = torch.cat(xa)
+            r2 = torch.cat(ra) if with_res else None
+            with view_groups(2):
+                y = bn(x2, r2, relu)
+            y.backward(torch.cat(dys))
+            ys = list(y.chunk(2))
+        else:
+            ys = [bn(xa[0], ra[0], relu), bn(xa[1], ra[1], relu)]
+            (ys[0] * dys[0]).sum().add((ys[1] * dys[1]).sum()).backward()
+        out.append(dict(y=[t.detach().clone() for t in ys], dx=[t.grad.clone() for t in xa],
+                        dr=[t.grad.clone() for t in ra] if with_res else [], dw=bn.weight.grad.clone(), db=bn.bias.grad.clone(),
+                        rm=bn.running_mean.clone(), rv=bn.running_var.clone(), nb=int(bn.num_batches_tracked)))
+    a, b = out
+    for k in ("y", "dx", "dr"):
+        for u, v in zip(a[k], b[k]):
+            assert torch.equal(u, v), k
+    assert torch.equal(a["rm"], b["rm"]) and torch.equal(a["rv"], b["rv"]) and a["nb"] == b["nb"] == 2
+    assert torch.allclose(a["dw"], b["dw"], rtol=1e-6, atol=1e-7) and torch.allclose(a["db"], b["db"], rtol=1e-6, atol=1e-7)
+
+
+def _rank_views(rank, world, port, path):
+    for p in (ROOT, PKG):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from contrast.sync_bn import FusedSyncBatchNorm, view_groups
+    dev = torch.device("cuda:0")
+    d = torch.load(path)
+    calls = {"all_gather": 0, "all_reduce": 0}
+    real_ag, real_ar = dist.all_gather, dist.all_reduce
+
+    def ag(*a, **k):
+        calls["all_gather"] += 1
+        return real_ag(*a, **k)
+
+    def ar(*a, **k):
+        calls["all_reduce"] += 1
+        return real_ar(*a, **k)
+    dist.all_gather, dist.all_reduce = ag, ar
+    sl = slice(0, 4) if rank == 0 else slice(4, 6)                    # unequal shards: 4 and 2 samples per view
+    res = {}
+    for batched in (False, True):
+        calls.update(all_gather=0, all_reduce=0)
+        bn = FusedSyncBatchNorm(d["x"].shape[2]).to(dev).train()
+        with torch.no_grad():
+            bn.weight.copy_(d["w"]); bn.bias.copy_(d["b"])
+        xs = [d["x"][v][sl].to(dev).contiguous(memory_format=CL).requires_grad_(True) for v in range(2)]
+        dys = [d["dy"][v][sl].to(dev).contiguous(memory_format=CL) for v in range(2)]
+        if batched:
+            with view_groups(2):
+                y = bn(torch.cat(xs), None, True)
+            y.backward(torch.cat(dys))
+            ys = list(y.chunk(2))
+        else:
+            ys = [bn(xs[0], None, True), bn(xs[1], None, True)]
+            (ys[0] * dys[0]).sum().add((ys[1] * dys[1]).sum()).backward()
+        res[batched] = dict(y=[t.detach().cpu() for t in ys], dx=[t.grad.cpu() for t in xs], rm=bn.running_mean.cpu(),
+                            rv=bn.running_var.cpu(), calls=dict(calls))
+    dist.all_gather, dist.all_reduce = real_ag, real_ar
+    torch.save(res, f"{path}.out{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_view_groups_halve_the_collectives_over_two_ranks(dev, tmp_path):
+    """Two gloo ranks sharing the GPU (unequal shards): batching the two views of a layer sends ONE all_gather and ONE
+    all_reduce instead of two each, and changes no value (statistics stay per view and global over the ranks)."""
+    g = torch.Generator().manual_seed(21)
+    shape = (2, 6, 32, 5, 5)                             # [view, sample, C, H, W]
+    d = dict(x=torch.randn(shape, generator=g) * 2 + 1, dy=torch.randn(shape, generator=g), w=torch.rand(32, generator=g) + 0.5,
+             b=torch.randn(32, generator=g))
+    d["x"][1] -= 1.5                                     # the views have different statistics
+    path = str(tmp_path / "views.pt")
+    torch.save(d, path)
+    mp.spawn(_rank_views, args=(2, _free_port(), path), nprocs=2, join=True)
+    for r in range(2):
+        o = torch.load(f"{path}.out{r}")
+        assert o[False]["calls"] == {"all_gather": 2, "all_reduce": 2}
+        assert o[True]["calls"] == {"all_gather": 1, "all_reduce": 1}
+        for k in ("y", "dx"):
+            for u, v in zip(o[False][k], o[True][k]):
+                assert torch.equal(u, v), k
+        assert torch.equal(o[False]["rm"], o[True]["rm"]) and torch.equal(o[False]["rv"], o[True]["rv"])
+
+
+def test_model_step_with_view_batching_matches_two_passes(dev):
+    """PixPro step with --bn-view-batch (one pass per encoder over both views) vs the reference's two passes: same loss,
+    pos_num, gradients and running statistics up to the convolutions' batch-size dependent summation order."""
+    import types
+    import importlib
+    pixpro_mod = importlib.import_module("contrast.models.PixPro")
+    from contrast import resnet
+    from contrast.synthetic import make_batch
+    out = []
+    for vb in (False, True):
+        torch.manual_seed(0)
+        margs = types.SimpleNamespace(pixpro_p=2.0, pixpro_momentum=0.99, pixpro_pos_ratio=0.7, pixpro_clamp_value=0.0,
+                                      pixpro_transform_layer=1, pixpro_ins_loss_weight=0.0, output_dir="/tmp",
+                                      num_instances=70000, batch_size=8, epochs=2000, start_epoch=1, feature_dim=256,
+                                      head_type="early_return", sync_bn=True, fused_bn=True, bn_view_batch=vb)
+        model = pixpro_mod.PixPro(resnet.resnet18, margs).to(dev).to(memory_format=CL).train()
+        d = make_batch(8, image_size=64, n_frames=2, frame_hw=(180, 320), device=dev, seed=7, with_flow=False)
+        im1, im2 = d[0].contiguous(memory_format=CL), d[1].contiguous(memory_format=CL)
+        loss, (a, b) = model(im1, im2, d[2], d[3])
+        loss.backward()
+        out.append((loss.item(), a[0].clone(), model.encoder.conv1.weight.grad.clone(),
+                    model.projector.linear2.weight.grad.clone(), model.encoder.bn1.running_var.clone(),
+                    model.encoder_k.layer4[1].bn2.running_mean.clone(), int(model.encoder.bn1.num_batches_tracked)))
+    assert abs(out[0][0] - out[1][0]) <= 1e-5 and torch.equal(out[0][1], out[1][1])
+    close(out[1][3], out[0][3], rel=2e-3)
+    close(out[1][2], out[0][2], rel=3e-2)
+    assert torch.allclose(out[0][4], out[1][4], rtol=1e-5) and torch.allclose(out[0][5], out[1][5], rtol=1e-4, atol=1e-6)
+    assert out[0][6] == out[1][6] == 2
+    with pytest.raises(ValueError, match="needs --fused-bn"):
+        pixpro_mod.PixPro(resnet.resnet18, types.SimpleNamespace(**{**vars(margs), "fused_bn": False}))
