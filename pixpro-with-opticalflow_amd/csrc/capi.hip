@@ -47,6 +47,10 @@ static int run_fused(const pixpro_problem& pb, const pixpro_dir* dirs, float* lo
   return run_fused_w8(pb, dirs, loss_n, pos_num, pos_mean, st);
 }
 size_t generic_workspace_bytes(const pixpro_problem& pb);
+bool tiled_supported(const pixpro_problem& pb);
+size_t tiled_workspace_bytes(const pixpro_problem& pb);
+int run_tiled(const pixpro_problem& pb, const pixpro_dir* dirs, float* loss_n, float* pos_num, float* pos_mean, float* loss,
+              void* workspace, size_t ws_bytes, hipStream_t st);
 int run_generic(const pixpro_problem& pb, const pixpro_dir* dirs, float* loss_n, float* pos_num, float* pos_mean,
                 float* loss, void* workspace, size_t ws_bytes, hipStream_t st, int mode);
 int run_finalize(const float* loss_n, float* loss, int B, int N, hipStream_t st);
@@ -126,7 +130,8 @@ const char* pixpro_last_error(void) { return g_err; }
 
 size_t pixpro_ppm_loss_workspace_bytes(const pixpro_problem* pb) {
   if (!pb || fused_supported(*pb)) return 0;
-  return generic_workspace_bytes(*pb);
+  const size_t g = generic_workspace_bytes(*pb), t = tiled_supported(*pb) ? tiled_workspace_bytes(*pb) : 0;
+  return g > t ? g : t;
 }
 
 size_t pixpro_ppm_loss_generic_workspace_bytes(const pixpro_problem* pb) {
@@ -158,7 +163,10 @@ int pixpro_ppm_loss(const pixpro_problem* pb, const pixpro_dir* dirs, float* los
     if (int e = run_fused(*pb, dirs, loss_n, pos_num, pos_mean, (hipStream_t)stream)) return e;
     return run_finalize(loss_n, loss, pb->N * pb->ndir, pb->N, (hipStream_t)stream);
   }
-  if (!workspace) return bad("this shape takes the staged path and needs a workspace");
+  if (!workspace) return bad("this shape takes a multi-launch path and needs a workspace");
+  // grids beyond 64 positions (14 x 14 at 448^2 crops): the tiled MFMA path, 7 launches; anything else: the staged path
+  if (tiled_supported(*pb) && aligned && !getenv("PIXPRO_NO_TILED"))
+    return run_tiled(*pb, dirs, loss_n, pos_num, pos_mean, loss, workspace, workspace_bytes, (hipStream_t)stream);
   return run_generic(*pb, dirs, loss_n, pos_num, pos_mean, loss, workspace, workspace_bytes, (hipStream_t)stream, 0);
 }
 

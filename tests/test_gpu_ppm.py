@@ -90,7 +90,7 @@ def _hotpath(dev, g, generic):
     return loss, pn, pm, preds, x1, x2, wv, bv
 
 
-@pytest.mark.parametrize("tag,generic", [("e2e7", False), ("e2e7", True), ("e2e14", True), ("e2e2", True)])
+@pytest.mark.parametrize("tag,generic", [("e2e7", False), ("e2e7", True), ("e2e14", True), ("e2e14", False), ("e2e2", True)])
 def test_hotpath_golden(dev, tag, generic):
     g = load_golden(f"hotpath_{tag}")
     loss, pn, pm, preds, x1, x2, wv, bv = _hotpath(dev, g, generic)
@@ -152,6 +152,10 @@ def _run_oracle(P, p=2.0, clamp=0.0):
     ((3, 256, 8, 8), False, 2.0, 0.0), ((3, 128, 5, 6), False, 2.0, 0.0), ((2, 256, 1, 1), False, 2.0, 0.0),
     ((3, 256, 7, 7), True, 2.0, 0.0), ((2, 64, 14, 14), True, 2.0, 0.0), ((3, 48, 3, 5), True, 0.5, 0.1),
     ((1, 256, 14, 14), True, 2.0, 0.0),
+    # generic=False with P > 64: the tiled 7-launch MFMA path (ppm_tiled.hip)
+    ((2, 64, 14, 14), False, 2.0, 0.0), ((1, 256, 14, 14), False, 2.0, 0.0), ((3, 128, 10, 10), False, 2.0, 0.0),
+    ((2, 256, 12, 12), False, 0.5, 0.1), ((2, 64, 9, 12), False, 3.0, 0.2), ((5, 128, 16, 17), False, 1.0, 0.0),
+    ((2, 192, 10, 10), False, 2.0, 0.0),                                   # C = 192: falls back to the staged path
 ])
 def test_ppm_loss_vs_oracle(dev, shape, generic, p, clamp):
     N, C, H, W = shape
@@ -352,7 +356,8 @@ def _full_size_problem(N, C, H, W, seed):
 
 
 @pytest.mark.parametrize("shape,generic", [
-    ((64, 256, 14, 14), True),      # BASELINE config 5 per-GPU size on the staged path (grid.z = 2N, blockIdx.x / N indexing)
+    ((64, 256, 14, 14), False),     # BASELINE config 5 per-GPU size: the tiled path (what the model runs at 448^2)
+    ((64, 256, 14, 14), True),      # ... and the staged path (grid.z = 2N, blockIdx.x / N indexing)
     ((256, 256, 7, 7), False),      # BASELINE config 2 size on the single-launch kernel, against the oracle (not the staged path)
     ((128, 256, 7, 7), False),      # config 3 per-GPU size
     ((64, 256, 7, 7), True),        # config 4 per-GPU size on the staged path
@@ -370,3 +375,28 @@ def test_full_size_vs_oracle(dev, shape, generic):
     assert (out[4][0].cpu() - p1).abs().max() <= 2e-6 and (out[4][1].cpu() - p2).abs().max() <= 2e-6
     for a, b in zip(gh, go):
         close(a, b)
+
+
+def test_tiled_equals_staged_and_properties(dev):
+    """14 x 14 grid: the tiled path against the staged path on the device, plus the size-independent properties
+    (all-false mask -> zero loss and gradients, linearity in the upstream gradient, forward-only call)."""
+    from contrast import ops
+    P = _random_problem(dev, 8, 256, 14, 14, 96, 128, seed=12)
+    ot, gt = _run_hip(dev, P, generic=False, want_pred=True)
+    og, gg = _run_hip(dev, P, generic=True, want_pred=True)
+    assert torch.equal(ot[1], og[1]) and torch.equal(ot[2], og[2])
+    assert abs(ot[0].item() - og[0].item()) <= 1e-5
+    assert (ot[4] - og[4]).abs().max().item() <= 2e-6
+    for a, b in zip(gt, gg):
+        close(a, b)
+    Pf = dict(P, mf=torch.zeros_like(P["mf"]), mb=torch.zeros_like(P["mb"]))
+    e, ge = _run_hip(dev, Pf)
+    assert e[1].sum().item() == 0 and e[0].item() == 0.0 and all(t.abs().max().item() == 0 for t in ge)
+    f, gf = _run_hip(dev, P, grad_scale=3.0)
+    for u, v in zip(gf, gt):
+        assert torch.allclose(u, 3.0 * v, rtol=1e-6, atol=1e-12)
+    q = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in P.items()}
+    with torch.no_grad():
+        d1 = ops.Direction(q["x1"], q["v1"], q["k2"], q["c1"], q["c2"], q["ff"], q["mf"], q["size"])
+        out = ops.ppm_loss([d1], 2.0, 0.0, 0.7, True)
+    assert torch.equal(out[1][0], ot[1][0])
