@@ -509,17 +509,32 @@ k_prepare_staged(const float* __restrict__ lo_fwd, const float* __restrict__ lo_
   __shared__ float2 nf[RH * RW];           // normalised forward flow of the region
   __shared__ float2 nb[RH * RW];           // normalised backward flow
   __shared__ float4 lw[LW_H * LW_W];       // low-res cells {fwd.x, fwd.y, bwd.x, bwd.y}, replicate-padded
-  // few tiles are marked, so the grid is small and every block scans its share of the tile list (an empty launch of
-  // one block per tile cost 0.17 ms at N = 256)
+  // Few tiles are marked: a small grid scans the tile list - block b owns tiles b, b + G, b + 2G, ... (marked tiles spread
+  // evenly over the blocks), checks NT of them per step (one mark byte per thread: one memory round trip per NT tiles, not
+  // per tile) and works through the marked ones.
+  __shared__ unsigned long long marks[NWAVE];
   const int t = threadIdx.x;
   const size_t hw = (size_t)g.h * g.w, HW = (size_t)g.Hf * g.Wf;
-  const int ntiles = tiles_x * tiles_y * N;
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-  const int n = tile / (tiles_x * tiles_y), rem = tile - n * tiles_x * tiles_y, by = rem / tiles_x, bx = rem - by * tiles_x;
+  const int ntiles = tiles_x * tiles_y * N, per_n = tiles_x * tiles_y;
+  const int G = gridDim.x;
+  for (int base = 0; blockIdx.x + (long)G * base < ntiles; base += NT) {
+  {
+    const long tl = blockIdx.x + (long)G * (base + t);
+    bool marked = false;
+    if (tl < ntiles) {
+      const int n_ = tl / per_n, rem_ = tl - n_ * per_n, by_ = rem_ / tiles_x, bx_ = rem_ - by_ * tiles_x;
+      marked = mask_fwd[(size_t)n_ * HW + (size_t)(by_ * TY) * g.Wf + bx_ * TX] == TILE_MARK;
+    }
+    const unsigned long long m = __ballot(marked);
+    if ((t & 63) == 0) marks[t >> 6] = m;
+  }
+  __syncthreads();                                            // also orders these reads before any mask write below
+  for (int wv = 0; wv < NWAVE; ++wv)
+  for (unsigned long long todo = marks[wv]; todo; todo &= todo - 1) {
+  const int tile = blockIdx.x + G * (base + 64 * wv + __builtin_ctzll(todo));
+  const int n = tile / per_n, rem = tile - n * per_n, by = rem / tiles_x, bx = rem - by * tiles_x;
   const int tx0 = bx * TX, ty0 = by * TY;
   const int rx0 = tx0 - HL, ry0 = ty0 - HL;
-  // every thread reads the mark before the first barrier; the first mask byte is written after the second one
-  if (mask_fwd[(size_t)n * HW + (size_t)ty0 * g.Wf + tx0] != TILE_MARK) continue;      // block-uniform
   const float* gf = lo_fwd + (size_t)n * 2 * hw;
   const float* gb = lo_bwd + (size_t)n * 2 * hw;
   // low-res window: first cell = the cell of the region's first (clamped) pixel
@@ -593,6 +608,8 @@ k_prepare_staged(const float* __restrict__ lo_fwd, const float* __restrict__ lo_
     if (badb) atomicAdd(&invalid[N + n], badb);
   }
   __syncthreads();                                          // the LDS images are reused by the next tile
+  }
+  __syncthreads();                                            // marks[] is rewritten by the next step
   }
 }
 
@@ -889,7 +906,7 @@ int run_flow_prepare(const float* lo_fwd, const float* lo_bwd, float* flow_fwd, 
       if (mask_fwd) {
         CHECKED("k_prepare_cert");
         const long ntiles = (long)grid.x * grid.y * N;
-        hipLaunchKernelGGL(k_prepare_staged, dim3((unsigned)(ntiles < 2048 ? ntiles : 2048)), dim3(NT), 0, st, lo_fwd,
+        hipLaunchKernelGGL(k_prepare_staged, dim3((unsigned)(ntiles < 1024 ? ntiles : 1024)), dim3(NT), 0, st, lo_fwd,
                            lo_bwd, mask_fwd, mask_bwd, invalid, N, g, (int)grid.x, (int)grid.y);
       }
     } else if (flow_up) {
