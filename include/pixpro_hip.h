@@ -91,8 +91,9 @@ const char* pixpro_last_error(void);
  * regression_loss (:92-247, incl. add_optical_flow :46-89) and their backward.
  * loss_n, pos_num, pos_mean: [ndir*N]; loss: [1] = sum over directions of -2*mean_n(loss_n)
  * (PixPro.py:247,431).  Gradients (if dx != NULL) are d(grad_scale*loss)/dx, /dv.
- * Uses the single-launch MFMA kernel when P<=64 and C%128==0 (C<=256), otherwise the
- * staged generic path (needs workspace). */
+ * Uses the single-launch MFMA kernel when P<=64 and C%128==0 (C<=256); larger grids (the 14x14
+ * grid of 448^2 crops) with C in {64,128,256} and P%4==0 take the tiled 7-launch MFMA path,
+ * anything else the staged generic path (both need the workspace). */
 size_t pixpro_ppm_loss_workspace_bytes(const pixpro_problem* pb);          /* 0 when the MFMA kernel applies */
 size_t pixpro_ppm_loss_generic_workspace_bytes(const pixpro_problem* pb);  /* staged path, any shape */
 int pixpro_ppm_loss(const pixpro_problem* pb, const pixpro_dir* dirs, float* loss_n,
@@ -149,9 +150,11 @@ int pixpro_fbc_mask(const float* flow_fwd, const float* flow_bwd, uint8_t* mask,
  * permute of util.py:183) -> composed flows [N,2,Hf,Wf] and masks uint8 [N,Hf,Wf]
  * (Hf,Wf = 8h,8w if flow_up else h,w).  masks nullable (alpha None).  invalid_count
  * (nullable) int32 [2*N]: number of invalid pixels per sample (fwd then bwd), the numerator
- * of calc_mask_ratio (util.py:360-366).  F1 == 1 (nframe 2): ONE launch, the only HBM
- * traffic is the low-res read and the output write; F1 > 1: one chain launch (up-sampling
- * evaluated lazily) + two mask launches.  No workspace. */
+ * of calc_mask_ratio (util.py:360-366).  F1 == 1 (nframe 2): two launches (flows + certified masks; the tiles the
+ * certificate cannot settle), the only HBM traffic is the low-res read and the output write; F1 > 1: one chain launch
+ * (up-sampling evaluated lazily) + one mask launch.  Both of ATen's CPU bilinear up-sampling orders are reproduced
+ * (switch at 8h + 8w = 128).  No workspace.  The environment variable PIXPRO_FLOW_PATH = auto | certified | staged
+ * selects between two bit-identical ways of producing the F1 == 1 masks (a testing / timing knob). */
 int pixpro_flow_prepare(const float* lo_fwd, const float* lo_bwd, float* flow_fwd,
                         float* flow_bwd, uint8_t* mask_fwd, uint8_t* mask_bwd,
                         int32_t* invalid_count, int32_t N, int32_t F1, int32_t h, int32_t w,
