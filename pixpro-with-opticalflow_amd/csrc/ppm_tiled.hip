@@ -26,7 +26,7 @@ constexpr int TSB = 80;          // LDS row stride of a 64-wide operand slab (co
 struct TlWs {                    // workspace carve (floats unless noted)
   float *rx, *rv, *rk;           // [B][P] reciprocal column norms
   float *cnt, *lpart;            // [B], [B][strips]
-  float *A, *Dm, *dSs;           // [B][P][P]
+  float *A, *Dm, *dSs, *Av;      // [B][P][P]; Av[s][i] = rv[s] A[s][i], dSs rows pre-scaled by rx
   float *dY;                     // [B][C][P]
   unsigned long long* bits;      // [B][P][W64]
 };
@@ -36,7 +36,7 @@ inline size_t al256(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
 size_t tl_bytes(const pixpro_problem& pb) {
   const size_t B = (size_t)pb.N * pb.ndir, P = (size_t)pb.H * pb.W, R = (size_t)pb.C * P, Q = P * P, W64 = (P + 63) / 64;
   const size_t strips = (P + 63) / 64;
-  return 3 * al256(B * P * 4) + al256(B * 4) + al256(B * strips * 4) + 3 * al256(B * Q * 4) + al256(B * R * 4) +
+  return 3 * al256(B * P * 4) + al256(B * 4) + al256(B * strips * 4) + 4 * al256(B * Q * 4) + al256(B * R * 4) +
          al256(B * P * W64 * 8) + 4096;
 }
 
@@ -49,6 +49,7 @@ TlWs tl_carve(void* ws, const pixpro_problem& pb) {
   w.rx = (float*)take(B * P * 4); w.rv = (float*)take(B * P * 4); w.rk = (float*)take(B * P * 4);
   w.cnt = (float*)take(B * 4); w.lpart = (float*)take(B * strips * 4);
   w.A = (float*)take(B * Q * 4); w.Dm = (float*)take(B * Q * 4); w.dSs = (float*)take(B * Q * 4);
+  w.Av = (float*)take(B * Q * 4);
   w.dY = (float*)take(B * R * 4);
   w.bits = (unsigned long long*)take(B * P * W64 * 8);
   return w;
@@ -232,6 +233,7 @@ __global__ void __launch_bounds__(TB) k_tl_gram(Dirs D, TlWs w, int N, int C, in
     f32x4 acc[2][2] = {{z, z}, {z, z}};
     gram_tile(acc, x, x, m0, n0, C, P, As, Bs);
     const float* rx = w.rx + (size_t)b * P;
+    const float* rv = w.rv + (size_t)b * P;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -245,6 +247,8 @@ __global__ void __launch_bounds__(TB) k_tl_gram(Dirs D, TlWs w, int N, int C, in
             pow_map(acc[i][j][r] * rx[gm] * rx[gn], p, clampv, a, d);
             w.A[(size_t)b * Q + (size_t)gm * P + gn] = a;
             w.Dm[(size_t)b * Q + (size_t)gm * P + gn] = d;
+            // the 1/||v|| of Y = v^ A folded into A's rows, so that the strip product stages v as it is
+            w.Av[(size_t)b * Q + (size_t)gm * P + gn] = rv[gm] * a;
           }
         }
       }
@@ -281,10 +285,12 @@ __global__ void __launch_bounds__(TB) k_tl_gram(Dirs D, TlWs w, int N, int C, in
     __syncthreads();
     const float* T2 = ti == tj ? L1 : L2;
     float* out = w.dSs + (size_t)b * Q;
+    const float* rx = w.rx + (size_t)b * P;     // the 1/||x|| of dX^ = x^ dSs folded into the rows of dSs
     for (int e = t; e < 64 * 64; e += TB) {
       const int r = e >> 6, c = e & 63;
-      if (i0 + r < P && j0 + c < P) out[(size_t)(i0 + r) * P + j0 + c] = L1[r * 65 + c] + T2[c * 65 + r];
-      if (ti != tj && j0 + r < P && i0 + c < P) out[(size_t)(j0 + r) * P + i0 + c] = L2[r * 65 + c] + L1[c * 65 + r];
+      if (i0 + r < P && j0 + c < P) out[(size_t)(i0 + r) * P + j0 + c] = rx[i0 + r] * (L1[r * 65 + c] + T2[c * 65 + r]);
+      if (ti != tj && j0 + r < P && i0 + c < P)
+        out[(size_t)(j0 + r) * P + i0 + c] = rx[j0 + r] * (L2[r * 65 + c] + L1[c * 65 + r]);
     }
   }
 }
@@ -292,29 +298,34 @@ __global__ void __launch_bounds__(TB) k_tl_gram(Dirs D, TlWs w, int N, int C, in
 // ---- C x 64 strips over K = P: all C rows of a strip of columns in one work-group -----------------------------------------
 // acc[mt][nt] += sum_k Aop(c, k) * Bop(k, n);  wave w owns rows [w*C/4, (w+1)*C/4) = MW 16-row tiles.
 // FA(c, k4): float4 of A for k = 4*k4 .. 4*k4+3 (k-fast source rows);  FB(k, n): scalar of B.
-template <int MW, class FA, class FB>
-__device__ __forceinline__ void strip_gemm(f32x4 (&acc)[MW][4], int C, int P, int nlive, float* As, float* Bs, FA fa,
-                                           FB fb) {
-  // A slab in LDS as [row][k], 20 floats per row: the source rows are k-contiguous, so four lanes fetch one row's 64 B
-  // (16 full segments per wave instruction) and store them as one 16-B LDS write; the MFMA operand reads are 2-way
-  // conflicted (rows r and r + 8 share banks), which at 8 reads per 16 MFMAs does not show.
+template <int MW, class FB>
+__device__ __forceinline__ void strip_gemm(f32x4 (&acc)[MW][4], int P, int nlive, float* As, float* Bs,
+                                           const float* __restrict__ Asrc, FB fb) {
+  // A operand: rows of Asrc ([64*MW][P], k-contiguous) as they are (every column scale of the products is folded into the
+  // P x P operand, see k_tl_gram).  A slab in LDS as [row][k], 20 floats per row: four lanes fetch one row's 64 B (16 full
+  // segments per wave instruction) and store them as one 16-B LDS write; the MFMA operand reads are 2-way conflicted
+  // (rows r and r + 8 share banks), which at 8 reads per 16 MFMAs does not show.
   constexpr int TSA = 20;
   const int t = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, lr = lane & 15, lq = lane >> 4;
   const int arow = t >> 2, ak4 = t & 3;      // + 64 rows per pass, MW passes
   const int bcol = t & 63, bk = t >> 6;
+  const float4* ap[MW];                      // this thread's float4 of the current slab, advanced by 4 float4 per slab
+#pragma unroll
+  for (int e = 0; e < MW; ++e) ap[e] = reinterpret_cast<const float4*>(Asrc + (size_t)(arow + 64 * e) * P) + ak4;
   float4 ra[MW];
   float rb[4];
   const int K4 = P / 4;
   auto request = [&](int k0) {
+    const bool full = k0 + 16 <= P;          // uniform: only the last slab of P = 196 checks bounds
 #pragma unroll
     for (int e = 0; e < MW; ++e) {
-      const int k4 = k0 / 4 + ak4;
-      ra[e] = k4 < K4 ? fa(arow + 64 * e, k4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      ra[e] = (full || k0 / 4 + ak4 < K4) ? *ap[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+      ap[e] += 4;
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int k = k0 + bk + 4 * e;
-      rb[e] = k < P ? fb(k, bcol) : 0.f;
+      rb[e] = (full || k < P) ? fb(k, bcol) : 0.f;
     }
   };
   request(0);
@@ -385,15 +396,11 @@ __global__ void __launch_bounds__(TB) k_tl_strip(pixpro_problem pb, Dirs D, TlWs
     const float* kk = dd.k + so;
     const float* rv = w.rv + (size_t)b * P;
     const float* rk = w.rk + (size_t)b * P;
-    const float* A = w.A + (size_t)b * Q;
-    // ---- Y = v^ A
-    strip_gemm<MW>(acc, C, P, nlive, As, Bs,
-                   [&](int c, int k4) {
-                     const float4 a = *reinterpret_cast<const float4*>(v + (size_t)c * P + 4 * k4);
-                     const float4 s = *reinterpret_cast<const float4*>(rv + 4 * k4);
-                     return make_float4(a.x * s.x, a.y * s.y, a.z * s.z, a.w * s.w);
-                   },
-                   [&](int k, int nl) { return n0 + nl < P ? A[(size_t)k * P + n0 + nl] : 0.f; });
+    const float* Av = w.Av + (size_t)b * Q;
+    (void)rv;
+    // ---- Y = v^ A = v (diag(rv) A): the column scale of v sits in the rows of Av, the loader is a plain copy
+    const bool cok = n0 + (t & 63) < P;        // this loader thread's column exists
+    strip_gemm<MW>(acc, P, nlive, As, Bs, v, [&](int k, int nl) { return cok ? Av[(size_t)k * P + n0 + nl] : 0.f; });
     float ry[4];
     {
       float s[4];
@@ -436,13 +443,9 @@ __global__ void __launch_bounds__(TB) k_tl_strip(pixpro_problem pb, Dirs D, TlWs
       for (int nn = 0; nn < 4; ++nn) G[m][nn] = z;
     const unsigned long long* brow = w.bits + ((size_t)b * P + min(n0 + (t & 63), P - 1)) * W64;
     const bool bok = n0 + (t & 63) < P;
-    strip_gemm<MW>(G, C, P, nlive, As, Bs,
-                   [&](int c, int k4) {
-                     const float4 a = *reinterpret_cast<const float4*>(kk + (size_t)c * P + 4 * k4);
-                     const float4 s = *reinterpret_cast<const float4*>(rk + 4 * k4);
-                     return make_float4(a.x * s.x, a.y * s.y, a.z * s.z, a.w * s.w);
-                   },
-                   [&](int k, int) { return bok ? (float)((brow[k >> 6] >> (k & 63)) & 1ull) : 0.f; });
+    // G = k^ M^T = k (diag(rk) M^T): the column scale of k rides on the expanded mask bits
+    strip_gemm<MW>(G, P, nlive, As, Bs, kk,
+                   [&](int k, int) { return (bok && ((brow[k >> 6] >> (k & 63)) & 1ull)) ? rk[k] : 0.f; });
     // ---- <Y^, G> per column, loss partial, dY
     float tc[4];
 #pragma unroll
@@ -477,25 +480,15 @@ __global__ void __launch_bounds__(TB) k_tl_strip(pixpro_problem pb, Dirs D, TlWs
       }
     }
   } else {
-    // blockIdx.z = 0: dV^ = dY A, dv = (dV^ - v^ s) / n_v ;  blockIdx.z = 1: dX^ = x^ dSs, dx = (dX^ - x^ s) / n_x
+    // blockIdx.z = 0: dV^ = dY A, dv = (dV^ - v^ s) / n_v ;  blockIdx.z = 1: dX^ = x^ dSs', dx = (dX^ - x^ s) / n_x
+    // (both products in one work-group - a loop over the two - compiles to 256 VGPRs and runs slower: 204 us vs 127 us)
     const bool isx = blockIdx.z == 1;
     const float* src = (isx ? dd.x : dd.v) + so;               // the tensor being differentiated
     const float* rn = (isx ? w.rx : w.rv) + (size_t)b * P;
     const float* Mat = (isx ? w.dSs : w.A) + (size_t)b * Q;
-    const float* dY = w.dY + (size_t)b * R;
-    if (isx) {
-      strip_gemm<MW>(acc, C, P, nlive, As, Bs,
-                     [&](int c, int k4) {
-                       const float4 a = *reinterpret_cast<const float4*>(src + (size_t)c * P + 4 * k4);
-                       const float4 s = *reinterpret_cast<const float4*>(rn + 4 * k4);
-                       return make_float4(a.x * s.x, a.y * s.y, a.z * s.z, a.w * s.w);
-                     },
-                     [&](int k, int nl) { return n0 + nl < P ? Mat[(size_t)k * P + n0 + nl] : 0.f; });
-    } else {
-      strip_gemm<MW>(acc, C, P, nlive, As, Bs,
-                     [&](int c, int k4) { return *reinterpret_cast<const float4*>(dY + (size_t)c * P + 4 * k4); },
-                     [&](int k, int nl) { return n0 + nl < P ? Mat[(size_t)k * P + n0 + nl] : 0.f; });
-    }
+    const float* Aop = isx ? src : w.dY + (size_t)b * R;
+    const bool cok = n0 + (t & 63) < P;
+    strip_gemm<MW>(acc, P, nlive, As, Bs, Aop, [&](int k, int nl) { return cok ? Mat[(size_t)k * P + n0 + nl] : 0.f; });
     float hat[MW][4][4];
     float s[4];
 #pragma unroll
