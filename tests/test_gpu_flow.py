@@ -146,3 +146,50 @@ def test_apply_optical_flow_bdd_size_batch_vs_oracle(dev, nfr, N):
         assert 0 < mfo[n].float().mean() < 1
     r = util.calc_mask_ratio(mf).cpu()
     assert torch.allclose(r, (~mfo).float().mean((-1, -2)), atol=1e-6, rtol=0)
+
+
+@pytest.mark.parametrize("case", ["nan", "inf", "huge", "alpha2_tiny", "alpha2_zero", "alpha1_zero", "alpha1_negative",
+                                  "coherent_40px", "coherent_18px", "motion_boundary", "zero"])
+def test_flow_prepare_adversarial_inputs_vs_oracle(dev, case):
+    """The certified nframe=2 kernel decides most mask bits from a bound; whatever the inputs do to that bound (NaN / Inf
+    cells, flows far beyond the window, tolerances that certify nothing, a motion boundary inside a tile) the bits must
+    stay the oracle's.  Several tiles per map (45x80 -> 360x640)."""
+    from contrast import util
+    from oracle import pixpro_oracle as O
+    from recipes import smooth_flow
+    gen = torch.Generator().manual_seed(77)
+    N, hw = 2, (45, 80)
+    fw = smooth_flow((N, 1, 2, *hw), 0.5, gen)
+    bw = -fw + smooth_flow((N, 1, 2, *hw), 0.05, gen)
+    a1, a2 = 0.01, 0.5
+    if case == "nan":
+        fw[0, 0, 0, 10, 20] = float("nan"); bw[1, 0, 1, 30, 50] = float("nan")
+    elif case == "inf":
+        fw[0, 0, 1, 5, 5] = float("inf"); bw[1, 0, 0, 40, 70] = -float("inf")
+    elif case == "huge":
+        fw[0] += 1e6; bw[1, 0, :, 20:30] -= 3e4
+    elif case == "alpha2_tiny":
+        a2 = 1e-6
+    elif case == "alpha2_zero":
+        a2 = 0.0
+    elif case == "alpha1_zero":
+        a1 = 0.0
+    elif case == "alpha1_negative":
+        a1 = -0.05
+    elif case == "coherent_40px":           # beyond what the cell window reaches: every tile goes to the staged kernel
+        fw[:, :, 0] += 5.0; bw[:, :, 0] -= 5.0
+    elif case == "coherent_18px":           # inside the window, far outside the 8-pixel halo of the staged kernel
+        fw[:, :, 1] += 2.25; bw[:, :, 1] -= 2.25
+    elif case == "motion_boundary":         # a step of 3 low-res pixels (24 px) through the middle of the tiles
+        fw[:, :, 0, :, 37:] += 3.0; bw[:, :, 0, :, 40:] -= 3.0
+    elif case == "zero":
+        fw.zero_(); bw.zero_()
+    size = torch.tensor([8 * hw[0], 8 * hw[1]])
+    (f, _, mf), (b, _, mb) = util.apply_optical_flow(_data(fw, bw, size, 2, dev), None, _args(True, alpha1=a1, alpha2=a2))
+    with O.aten_samplers():
+        (fo, _, mfo), (bo, _, mbo) = O.apply_optical_flow_file(fw, bw, size, True, a1, a2)
+    assert torch.equal(torch.nan_to_num(f.cpu(), nan=123.0), torch.nan_to_num(fo, nan=123.0))
+    assert torch.equal(torch.nan_to_num(b.cpu(), nan=123.0), torch.nan_to_num(bo, nan=123.0))
+    assert torch.equal(mf.cpu(), mfo) and torch.equal(mb.cpu(), mbo)
+    r = util.calc_mask_ratio(mf).cpu()
+    assert torch.allclose(r, (~mfo).float().mean((-1, -2)), atol=1e-6, rtol=0)
