@@ -202,7 +202,8 @@ constexpr int RW = TX + HL + HR, RH = TY + HL + HR;          // 80 x 56
 constexpr int NGROUP = 8;                                     // row groups of the staging loop
 constexpr int NT = (NGROUP + NGROUP / 4) * 64, NWAVE = NT / 64;   // 8 waves stage the tile columns, 2 the halo columns
 constexpr int ROWS_PER_GROUP = RH / NGROUP;                   // 7 region rows per staging thread
-constexpr int LW_W = RW / 8 + 4, LW_H = RH / 8 + 4;           // low-res window (replicate-padded): 14 x 11 cells
+constexpr int LMARG = 3;                                      // extra cells around the region's cells: taps up to ~ +-32 px away
+constexpr int LW_W = RW / 8 + 4 + 2 * LMARG, LW_H = RH / 8 + 4 + 2 * LMARG;   // low-res window (replicate-padded): 20 x 17 cells
 static_assert(RH % NGROUP == 0 && TY % NWAVE == 0 && (RW - TX) * 4 == 64 && NGROUP % 4 == 0,
               "thread mapping of the staging loop");
 
@@ -251,6 +252,42 @@ __device__ __forceinline__ bool fbc_staged(float2 fn, const float2* __restrict__
   return (cyc - eps) <= 0.f;
 }
 
+// The same decision from the low-res CELLS in LDS (4 taps x separable up-sampling + exact normalisation, ~120 VALU): the
+// middle path between the staged region / the certificate and the generic evaluation from global memory.  `cell(ry, rx)`
+// returns the opposite flow's cell at window coordinates; the window holds cw_h x cw_w cells from (cwy0, cwx0).
+template <class Cell>
+__device__ __forceinline__ bool fbc_cells(float2 fn, const Up8Geom& g, float c0x, float c0y, int cwx0, int cwy0, int cw_w,
+                                          int cw_h, Cell cell, bool& slow) {
+  const float c1x = c0x + fn.x, c1y = c0y + fn.y;
+  if (!((fabsf(c1x) < 1.f) && (fabsf(c1y) < 1.f))) return false;
+  const float ix = (c1x + 1.f) * g.hx, iy = (c1y + 1.f) * g.hy;
+  const float xw = floorf(ix), yn = floorf(iy);
+  const float w = ix - xw, e = 1.f - w, n = iy - yn, s = 1.f - n;
+  const int x0 = (int)xw, y0 = (int)yn;
+  // x0 + 1 == Wf (y0 + 1 == Hf) only when the weight w (n) is exactly 0: the clamped duplicate is finite
+  const AxF ax[2] = {axf(x0, g.sx), axf(min(x0 + 1, g.Wf - 1), g.sx)};
+  const AxF ay[2] = {axf(y0, g.sy), axf(min(y0 + 1, g.Hf - 1), g.sy)};
+  const int rx0 = ax[0].i0 - cwx0, rx1 = ax[1].i0 - cwx0, ry0 = ay[0].i0 - cwy0, ry1 = ay[1].i0 - cwy0;
+  if (!(rx0 >= 0 && rx1 < cw_w - 1 && ry0 >= 0 && ry1 < cw_h - 1)) { slow = true; return false; }
+  float tx[4], ty[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const AxF& qy = ay[k >> 1];
+    const AxF& qx = ax[k & 1];
+    const int ry = (k >> 1) ? ry1 : ry0, rx = (k & 1) ? rx1 : rx0;
+    const float2 a = cell(ry, rx), b = cell(ry, rx + 1), c = cell(ry + 1, rx), d = cell(ry + 1, rx + 1);
+    tx[k] = div_c(16.f * up8_col(up8_row(a.x, b.x, qx.l0, qx.l1), up8_row(c.x, d.x, qx.l0, qx.l1), qy.l0, qy.l1), g.wd);
+    ty[k] = div_c(16.f * up8_col(up8_row(a.y, b.y, qx.l0, qx.l1), up8_row(c.y, d.y, qx.l0, qx.l1), qy.l0, qy.l1), g.ht);
+  }
+  const float nw = s * e, ne = s * w, sw = n * e, se = n * w;
+  const float bx = __builtin_fmaf(tx[3], se, __builtin_fmaf(tx[2], sw, __builtin_fmaf(tx[1], ne, tx[0] * nw)));
+  const float by = __builtin_fmaf(ty[3], se, __builtin_fmaf(ty[2], sw, __builtin_fmaf(ty[1], ne, ty[0] * nw)));
+  const float cx = fn.x + bx, cy = fn.y + by;
+  const float cyc = cx * cx + cy * cy;
+  const float eps = g.alpha1 * ((fn.x * fn.x + fn.y * fn.y) + (bx * bx + by * by)) + g.a2;
+  return (cyc - eps) <= 0.f;
+}
+
 // ---- fused file-mode apply_optical_flow, nframe = 2: both composed flows + both masks ------------------------------
 // k_prepare_cert writes the flows of every tile and the masks of every tile it can CERTIFY; the rest it marks for
 // k_prepare_staged.  The certificate: a pixel of direction d is valid iff it stays inside the frame and
@@ -269,7 +306,7 @@ __device__ __forceinline__ bool fbc_staged(float2 fn, const float2* __restrict__
 // ~12 instructions per direction - no taps, no halo.
 constexpr int TYC = 2 * TY;                              // a certified tile = two staged tiles on top of each other
 constexpr int W0_W = TX / 8 + 4, W0_H = TYC / 8 + 4;     // low-res cells under a tile: at most 12 x 14
-constexpr int MARG = 4;                                  // cells of margin around them: own flows up to ~ +-24 px
+constexpr int MARG = 4;                                  // cells of margin around them: own flow RANGE up to ~48 px
 constexpr int WW = W0_W + 2 * MARG, WH = W0_H + 2 * MARG;   // cell window: 20 x 22
 constexpr float BOX_SLOP = 1e-5f;
 constexpr uint8_t TILE_MARK = 0xFF;                      // first mask byte of a tile left to k_prepare_staged
@@ -309,6 +346,7 @@ k_prepare_cert(const float* __restrict__ lo_fwd, const float* __restrict__ lo_bw
                float* __restrict__ flow_bwd, uint8_t* __restrict__ mask_fwd, uint8_t* __restrict__ mask_bwd,
                int32_t* __restrict__ invalid, int N, Up8Geom g, int force) {
   __shared__ float4 cw[WH * WW];           // cells {fwd.x, fwd.y, bwd.x, bwd.y} under the tile + margin, replicate-padded
+  __shared__ float2 tw[2][WH * WW];        // target cells of a DISPLACED window (large coherent motion), per direction
   __shared__ float4 tmp[2][WH * W0_W];     // row pass {min x, max x, min y, max y} of the opposite flow
   __shared__ float4 tab[2][W0_H * W0_W];   // per own cell: normalised, inflated box {Lx, Ux, Ly, Uy} of the opposite flow
   __shared__ float part0[NWAVE_C][8];      // per-wave {min, max} x 4 channels of the cells under the tile
@@ -348,6 +386,8 @@ k_prepare_cert(const float* __restrict__ lo_fwd, const float* __restrict__ lo_bw
   }
   __syncthreads();
   bool certify = mask_fwd != nullptr && force != 2;       // block-uniform throughout
+  int shx[2] = {0, 0}, shy[2] = {0, 0};                   // displacement of the target window, in cells
+  bool shifted = false;
   if (mask_fwd != nullptr) {                              // uniform: the barriers below are reached by every thread
     int ox[2] = {0, 0}, oy[2] = {0, 0}, ex[2] = {0, 0}, ey[2] = {0, 0};    // first / last cell offset per axis, per direction
     certify = certify && odd_cells == 0;
@@ -366,19 +406,45 @@ k_prepare_cert(const float* __restrict__ lo_fwd, const float* __restrict__ lo_bw
       if (certify) {
         cell_offsets(lo[0], hi[0], g.sx, ox[d], ex[d]);
         cell_offsets(lo[1], hi[1], g.sy, oy[d], ey[d]);
-        // the neighbourhood of every cell under the tile has to lie inside the window
-        certify = ox[d] >= -MARG && ex[d] <= MARG + (W0_W - ucols) && oy[d] >= -MARG && ey[d] <= MARG + (W0_H - urows);
+        // The neighbourhood of every cell under the tile has to lie inside a 20 x 22 cell window.  Around the tile itself
+        // (the window that is already in LDS) that holds for own flows up to ~ +-24 px; a tile that moves further as a
+        // whole (fast ego-motion) gets a second window displaced by (shx, shy) cells, centred on where it lands.
+        const int span_x = MARG + (W0_W - ucols), span_y = MARG + (W0_H - urows);
+        certify = ex[d] - ox[d] <= MARG + span_x && ey[d] - oy[d] <= MARG + span_y;
+        shx[d] = min(max((ox[d] + ex[d]) / 2, ex[d] - span_x), ox[d] + MARG);
+        shy[d] = min(max((oy[d] + ey[d]) / 2, ey[d] - span_y), oy[d] + MARG);
+        if (ox[d] >= -MARG && ex[d] <= span_x && oy[d] >= -MARG && ey[d] <= span_y) shx[d] = shy[d] = 0;
       }
     }
     certify = uniform(certify);
+    shifted = uniform(certify && (shx[0] | shy[0] | shx[1] | shy[1]) != 0);
+    if (shifted) {                                        // second, displaced window of the opposite map (one more round trip)
+      for (int e = t; e < 2 * WH * WW; e += NT_C) {
+        const int d = e >= WH * WW, q = e - d * WH * WW, r = q / WW, c = q - r * WW;
+        const float* gm = d ? gf : gb;
+        const unsigned o = min(max(wy0 - MARG + shy[d] + r, 0), g.h - 1) * g.w + min(max(wx0 - MARG + shx[d] + c, 0), g.w - 1);
+        const float vx = gm[o], vy = gm[hw + o];
+        tw[d][q] = make_float2(vx, vy);
+        if (!(fabsf(vx) < INF && fabsf(vy) < INF)) odd_cells = 1;
+      }
+      __syncthreads();
+      certify = uniform(certify && odd_cells == 0);
+    }
     if (certify) {                                        // row pass: min / max over cells j + ox .. j + ex of each row
       for (int e = t; e < 2 * WH * W0_W; e += NT_C) {
         const int d = e >= WH * W0_W, q = e - d * WH * W0_W, r = q / W0_W, j = q - r * W0_W;
-        if (r >= MARG + oy[d] && r <= MARG + urows - 1 + ey[d] && j < ucols) {
+        // window row r holds cell row wy0 - MARG + shy + r; own cell row i needs rows MARG + i + oy - shy .. + ey - shy
+        if (r >= MARG + oy[d] - shy[d] && r <= MARG + urows - 1 + ey[d] - shy[d] && j < ucols) {
           float4 m = make_float4(INF, -INF, INF, -INF);
-          for (int k = ox[d]; k <= ex[d]; ++k) {
-            const float4 v = cw[r * WW + MARG + j + k];
-            const float vx = d ? v.x : v.z, vy = d ? v.y : v.w;          // fwd pixels (d = 0) sample the bwd flow
+          for (int k = ox[d] - shx[d]; k <= ex[d] - shx[d]; ++k) {
+            float vx, vy;
+            if (shifted) {
+              const float2 v = tw[d][r * WW + MARG + j + k];
+              vx = v.x; vy = v.y;
+            } else {
+              const float4 v = cw[r * WW + MARG + j + k];
+              vx = d ? v.x : v.z; vy = d ? v.y : v.w;              // fwd pixels (d = 0) sample the bwd flow
+            }
             m.x = fminf(m.x, vx); m.y = fmaxf(m.y, vx); m.z = fminf(m.z, vy); m.w = fmaxf(m.w, vy);
           }
           tmp[d][q] = m;
@@ -391,7 +457,7 @@ k_prepare_cert(const float* __restrict__ lo_fwd, const float* __restrict__ lo_bw
         const int d = e >= W0_H * W0_W, q = e - d * W0_H * W0_W, i = q / W0_W, j = q - i * W0_W;
         if (i < urows && j < ucols) {
           float4 m = make_float4(INF, -INF, INF, -INF);
-          for (int k = oy[d]; k <= ey[d]; ++k) {
+          for (int k = oy[d] - shy[d]; k <= ey[d] - shy[d]; ++k) {
             const float4 v = tmp[d][(MARG + i + k) * W0_W + j];
             m.x = fminf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fminf(m.z, v.z); m.w = fmaxf(m.w, v.w);
           }
@@ -476,8 +542,9 @@ k_prepare_cert(const float* __restrict__ lo_fwd, const float* __restrict__ lo_bw
     badf += __popcll(__ballot(act && !ok[0]));
     badb += __popcll(__ballot(act && !ok[1]));
   }
-  // pixels the certificate could not settle: the exact generic evaluation (kept out of the loop above so that the call
-  // does not dictate its register allocation)
+  // Pixels the certificate could not settle (rare in a tile that was not handed over): the exact generic evaluation, kept
+  // out of the loop above so that the call does not dictate its register allocation.  (Handing such tiles to the staged
+  // kernel instead makes this kernel leaner - 46 VGPRs - but re-does whole tiles for a few pixels: 0.96 vs 0.88 ms.)
   if (!act) undecided = 0;
   while (__any(undecided != 0)) {
     bool fixed_f = false, fixed_b = false;
@@ -537,11 +604,11 @@ k_prepare_staged(const float* __restrict__ lo_fwd, const float* __restrict__ lo_
   const int rx0 = tx0 - HL, ry0 = ty0 - HL;
   const float* gf = lo_fwd + (size_t)n * 2 * hw;
   const float* gb = lo_bwd + (size_t)n * 2 * hw;
-  // low-res window: first cell = the cell of the region's first (clamped) pixel
-  const int wx0 = axf(max(rx0, 0), g.sx).i0, wy0 = axf(max(ry0, 0), g.sy).i0;
+  // low-res window: the cells of the region's (clamped) pixels plus LMARG cells all around (for taps beyond the region)
+  const int wx0 = axf(max(rx0, 0), g.sx).i0 - LMARG, wy0 = axf(max(ry0, 0), g.sy).i0 - LMARG;
   for (int e = t; e < LW_H * LW_W; e += NT) {
     const int r = e / LW_W, c = e - r * LW_W;
-    const unsigned o = min(wy0 + r, g.h - 1) * g.w + min(wx0 + c, g.w - 1);
+    const unsigned o = min(max(wy0 + r, 0), g.h - 1) * g.w + min(max(wx0 + c, 0), g.w - 1);
     lw[e] = make_float4(gf[o], gf[hw + o], gb[o], gb[hw + o]);
   }
   __syncthreads();
@@ -594,8 +661,19 @@ k_prepare_staged(const float* __restrict__ lo_fwd, const float* __restrict__ lo_
       bool slowf = false, slowb = false;
       okf = fbc_staged(nf[o], nb, g, c0x, c0y, rx0, ry0, slowf);
       okb = fbc_staged(nb[o], nf, g, c0x, c0y, rx0, ry0, slowb);
-      if (__builtin_expect(slowf, 0)) okf = fbc_generic(gf, gb, g.h, g.w, y, x, g.alpha1, g.a2);
-      if (__builtin_expect(slowb, 0)) okb = fbc_generic(gb, gf, g.h, g.w, y, x, g.alpha1, g.a2);
+      // taps beyond the staged region: from the cells in LDS (up to ~32 px away), beyond those from global memory
+      if (__builtin_expect(slowf, 0)) {
+        bool far = false;
+        okf = fbc_cells(nf[o], g, c0x, c0y, wx0, wy0, LW_W, LW_H,
+                        [&](int ry, int rx) { const float4 v = lw[ry * LW_W + rx]; return make_float2(v.z, v.w); }, far);
+        if (far) okf = fbc_generic(gf, gb, g.h, g.w, y, x, g.alpha1, g.a2);
+      }
+      if (__builtin_expect(slowb, 0)) {
+        bool far = false;
+        okb = fbc_cells(nb[o], g, c0x, c0y, wx0, wy0, LW_W, LW_H,
+                        [&](int ry, int rx) { const float4 v = lw[ry * LW_W + rx]; return make_float2(v.x, v.y); }, far);
+        if (far) okb = fbc_generic(gb, gf, g.h, g.w, y, x, g.alpha1, g.a2);
+      }
       const size_t q = (size_t)n * HW + (size_t)y * g.Wf + x;
       mask_fwd[q] = okf ? 1 : 0;
       mask_bwd[q] = okb ? 1 : 0;

@@ -30,6 +30,9 @@ def main():
     ap.add_argument("--grid", type=int, default=7)
     ap.add_argument("--n-frames", type=int, default=2)
     ap.add_argument("--what", default="flow,ppm,ppm_generic,ema,lars")
+    ap.add_argument("--flow-offset", type=float, default=0.0, help="constant added to the forward flow's x component (full-res "
+                                                                    "pixels; the backward flow gets the negative): coherent motion")
+    ap.add_argument("--flow-step", type=float, default=0.0, help="motion boundary: this many pixels added right of the middle")
     a = ap.parse_args()
     import types
     from contrast import ops, util
@@ -37,6 +40,11 @@ def main():
     dev = torch.device("cuda:0")
     N, G = a.batch, a.grid
     data = make_batch(N, image_size=8, n_frames=a.n_frames, device=dev)
+    if a.flow_offset or a.flow_step:
+        _, lo_f, lo_b = data[5]
+        lo_f[:, :, 0] += a.flow_offset / 8.0; lo_b[:, :, 0] -= a.flow_offset / 8.0
+        half = lo_f.shape[-1] // 2
+        lo_f[:, :, 0, :, half:] += a.flow_step / 8.0; lo_b[:, :, 0, :, half:] -= a.flow_step / 8.0
     args = types.SimpleNamespace(alpha1=0.01, alpha2=0.5, use_flow_frames=False, use_flow_file=True, flow_up=True,
                                  flow_cat_norm=False, debug=False)
     A = 720 * 1280 * 4
