@@ -27,25 +27,9 @@ int check_launch(const char* what) {
 }
 
 // implemented in the kernel translation units
-bool fused_supported_w8(const pixpro_problem& pb);
-bool fused_supported_w16(const pixpro_problem& pb);
-int run_fused_w8(const pixpro_problem& pb, const pixpro_dir* dirs, float* loss_n, float* pos_num, float* pos_mean,
-                 hipStream_t st);
-int run_fused_w16(const pixpro_problem& pb, const pixpro_dir* dirs, float* loss_n, float* pos_num, float* pos_mean,
-                  hipStream_t st);
-// PIXPRO_FUSED_WAVES=16 selects the 1024-thread variant where the shape allows (A/B timing: 117 us vs 112 us at
-// N=256, i.e. no gain from more waves - the kernel is bound by its phase structure); default: 8 waves
-static int fused_waves_pref() {
-  static const int pref = [] { const char* e = getenv("PIXPRO_FUSED_WAVES"); return e ? atoi(e) : 8; }();
-  return pref;
-}
-static bool fused_supported(const pixpro_problem& pb) { return fused_supported_w16(pb) || fused_supported_w8(pb); }
-static int run_fused(const pixpro_problem& pb, const pixpro_dir* dirs, float* loss_n, float* pos_num, float* pos_mean,
-                     hipStream_t st) {
-  if (pb.layout == 0 && fused_supported_w16(pb) && (fused_waves_pref() == 16 || !fused_supported_w8(pb)))
-    return run_fused_w16(pb, dirs, loss_n, pos_num, pos_mean, st);
-  return run_fused_w8(pb, dirs, loss_n, pos_num, pos_mean, st);
-}
+bool fused_supported(const pixpro_problem& pb);
+int run_fused(const pixpro_problem& pb, const pixpro_dir* dirs, float* loss_n, float* pos_num, float* pos_mean,
+              hipStream_t st);
 size_t generic_workspace_bytes(const pixpro_problem& pb);
 bool tiled_supported(const pixpro_problem& pb);
 size_t tiled_workspace_bytes(const pixpro_problem& pb);
@@ -157,8 +141,8 @@ int pixpro_ppm_loss(const pixpro_problem* pb, const pixpro_dir* dirs, float* los
     const uintptr_t bits = (uintptr_t)q.x | (uintptr_t)q.v | (uintptr_t)q.k | (uintptr_t)q.dx | (uintptr_t)q.dv;
     if (bits & 15) aligned = false;
   }
-  if (pb->layout == 1 && !(fused_supported_w8(*pb) && aligned))
-    return bad("NHWC tiles are handled by the single-launch kernel only (P <= 64, C in {128, 256}, 16-B aligned)");
+  if (pb->layout == 1 && !(fused_supported(*pb) && aligned))
+    return bad("NHWC tiles are handled by the single-launch kernel only (P <= 49, C in {128, 256}, 16-B aligned)");
   if (fused_supported(*pb) && aligned) {
     if (int e = run_fused(*pb, dirs, loss_n, pos_num, pos_mean, (hipStream_t)stream)) return e;
     return run_finalize(loss_n, loss, pb->N * pb->ndir, pb->N, (hipStream_t)stream);

@@ -67,6 +67,22 @@ __device__ __forceinline__ Crop crop_of(const float* c, int H, int W) {
   return g;
 }
 
+// The same from a work-group-uniform address, read through the scalar cache (constant address space => s_load): a
+// vector load here queues behind whatever the CU's other waves have already requested - in the fused loss kernel the
+// whole x tile, ~10 k cycles.
+typedef const float __attribute__((address_space(4))) * sc_float_ptr;
+typedef const int __attribute__((address_space(4))) * sc_int_ptr;
+__device__ __forceinline__ Crop crop_of_uniform(const float* c, int H, int W) {
+  sc_float_ptr s = (sc_float_ptr)(uintptr_t)c;
+  const float c0 = s[0], c1 = s[1], c2 = s[2], c3 = s[3];
+  Crop g;
+  g.bw = (c2 - c0) / (float)W;
+  g.bh = (c3 - c1) / (float)H;
+  g.x0 = c0;
+  g.y0 = c1;
+  return g;
+}
+
 __device__ __forceinline__ float bin_diag(const Crop& g, float wo1, float ho1) {
   float a = g.bw * wo1, b = g.bh * ho1;
   return sqrtf(a * a + b * b);
@@ -230,6 +246,58 @@ __device__ __forceinline__ void displace_point(const float* __restrict__ flow_n,
   float fx, fy;
   bilinear2(FetchDense{flow_n, flow_n + (size_t)g.Hf * g.Wf, g.Wf}, g.Hf, g.Wf, gx, gy, TapNone(), fx, fy);
   valid = mask_n ? nearest_mask(mask_n, g.Hf, g.Wf, gx, gy) : true;
+  if (g.diff) {
+    ox = (x * g.rw + fx) / g.rw;
+    oy = (y * g.rh + fy) / g.rh;
+  } else {
+    ox = x + fx;
+    oy = y + fy;
+  }
+}
+
+// displace_point in two halves for callers that have something to do while the taps are in flight (the fused loss
+// kernel): `displace_fetch` requests all eight flow taps and the mask byte up front on clamped indices - one memory
+// round trip instead of five dependent ones (bilinear2 fetches each tap under its own branch) - and
+// `displace_finish` selects / combines exactly as displace_point does (a tap outside the map contributes 0 * weight).
+struct PointTaps {
+  BilinGeom b;
+  float ax, ay, bx, by, cx, cy, dx, dy;
+  bool m_in, has_mask;
+  uint8_t m;
+};
+__device__ __forceinline__ PointTaps displace_fetch(const float* __restrict__ flow_n, const uint8_t* __restrict__ mask_n,
+                                                    const FlowGeom& g, float x, float y) {
+  const float gx = 2.f * (x / g.wo1) - 1.f;
+  const float gy = 2.f * (y / g.ho1) - 1.f;
+  PointTaps t;
+  t.b = bilin_geom(g.Hf, g.Wf, gx, gy);
+  const int xa = min(max(t.b.x0, 0), g.Wf - 1), xb = min(max(t.b.x0 + 1, 0), g.Wf - 1);
+  const int ya = min(max(t.b.y0, 0), g.Hf - 1), yb = min(max(t.b.y0 + 1, 0), g.Hf - 1);
+  const float* __restrict__ px = flow_n;
+  const float* __restrict__ py = flow_n + (size_t)g.Hf * g.Wf;
+  t.ax = px[ya * g.Wf + xa]; t.ay = py[ya * g.Wf + xa];
+  t.bx = px[ya * g.Wf + xb]; t.by = py[ya * g.Wf + xb];
+  t.cx = px[yb * g.Wf + xa]; t.cy = py[yb * g.Wf + xa];
+  t.dx = px[yb * g.Wf + xb]; t.dy = py[yb * g.Wf + xb];
+  // nearest_mask's position
+  const float ix = (gx + 1.f) * ((float)(g.Wf - 1) / 2.f);
+  const float iy = (gy + 1.f) * ((float)(g.Hf - 1) / 2.f);
+  const float xr = rintf(ix), yr = rintf(iy);
+  t.m_in = xr >= 0.f && xr < (float)g.Wf && yr >= 0.f && yr < (float)g.Hf;
+  // unconditional byte load (no branch => no wait on the loads above): without a mask, some readable byte of the flow
+  const uint8_t* __restrict__ mp = mask_n ? mask_n : reinterpret_cast<const uint8_t*>(flow_n);
+  t.m = mp[t.m_in ? (int)yr * g.Wf + (int)xr : 0];       // raw byte: any use of it here would wait for the load
+  t.has_mask = mask_n != nullptr;
+  return t;
+}
+__device__ __forceinline__ void displace_finish(const PointTaps& t, const FlowGeom& g, float x, float y, float& ox,
+                                                float& oy, bool& valid) {
+  const int in = t.b.in;
+  const float fx = bilin_combine(t.b, (in & 1) ? t.ax : 0.f, (in & 2) ? t.bx : 0.f, (in & 4) ? t.cx : 0.f,
+                                 (in & 8) ? t.dx : 0.f);
+  const float fy = bilin_combine(t.b, (in & 1) ? t.ay : 0.f, (in & 2) ? t.by : 0.f, (in & 4) ? t.cy : 0.f,
+                                 (in & 8) ? t.dy : 0.f);
+  valid = t.has_mask ? (t.m_in && t.m != 0) : true;
   if (g.diff) {
     ox = (x * g.rw + fx) / g.rw;
     oy = (y * g.rh + fy) / g.rh;
@@ -427,6 +495,12 @@ __device__ __forceinline__ void frame_size(const pixpro_problem& pb, const pixpr
   if (d.size_dev) { Ho = d.size_dev[0]; Wo = d.size_dev[1]; }
   else if (pb.Ho > 0) { Ho = pb.Ho; Wo = pb.Wo; }
   else { Ho = (int)d.coord_q[9]; Wo = (int)d.coord_q[8]; }
+}
+
+__device__ __forceinline__ void frame_size_uniform(const pixpro_problem& pb, const pixpro_dir& d, int& Ho, int& Wo) {
+  if (d.size_dev) { sc_int_ptr s = (sc_int_ptr)(uintptr_t)d.size_dev; Ho = s[0]; Wo = s[1]; }
+  else if (pb.Ho > 0) { Ho = pb.Ho; Wo = pb.Wo; }
+  else { sc_float_ptr s = (sc_float_ptr)(uintptr_t)d.coord_q; Ho = (int)s[9]; Wo = (int)s[8]; }
 }
 
 // A = clamp(S,min=c) (+1e-6 if p<1) ** p  and  D = dA/dS  (PixPro.py:355-358).

@@ -20,36 +20,28 @@
 
 namespace pixpro {
 
-// The translation unit is compiled twice (Makefile): PIXPRO_NW = 8 (512-thread work-groups, C = 128 or 256) and
-// PIXPRO_NW = 16 (1024 threads, 4 waves per SIMD, C = 256: more waves to cover LDS / barrier latency inside the
-// single work-group a CU can hold).
-#ifndef PIXPRO_NW
-#define PIXPRO_NW 8
-#endif
-#define PIXPRO_CAT2(a, b) a##b
-#define PIXPRO_CAT(a, b) PIXPRO_CAT2(a, b)
-#define WFN(name) PIXPRO_CAT(name##_w, PIXPRO_NW)
-
 #ifdef PIXPRO_STAMPS   // diagnostic build only (tools/ppm_phase_stamps.py): wave 0 of block 0 stamps s_memtime
-#if PIXPRO_NW == 16
 __device__ unsigned long long g_stamps[64];
-#else
-extern __device__ unsigned long long g_stamps[64];
-#endif
 #define STAMP(i)                                                                            \
   do {                                                                                      \
-    if (blockIdx.x == 0 && threadIdx.x == 0) g_stamps[i] = __builtin_amdgcn_s_memtime();    \
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) g_stamps[i] = __builtin_amdgcn_s_memtime();    \
+  } while (0)
+#define STAMPW(i, t)                                                                        \
+  do {                                                                                      \
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == (t)) g_stamps[i] = __builtin_amdgcn_s_memtime();  \
   } while (0)
 #else
 #define STAMP(i)
+#define STAMPW(i, t)
 #endif
 
 namespace {
 
-constexpr int NWAVES = PIXPRO_NW;
+constexpr int NWAVES = 8;
 constexpr int NTHREADS = NWAVES * WAVE;
 constexpr int LS = 81;    // row stride of the small P x P matrices: odd, so rows AND columns (dS^T) spread over the banks
-constexpr int PF = PIXPRO_NW == 16 ? 4 : 7;   // float4 prefetch registers per thread: PF * NTHREADS * 4 >= 256 * 49
+constexpr int NLOAD = NTHREADS - WAVE;   // waves 1..7 stream the tiles; wave 0 works out the sample points meanwhile
+constexpr int PF = 7;     // float4 prefetch registers per loader thread: PF * NLOAD * 4 = 256 * 49 exactly
 constexpr int KU = 8;     // k-unroll of the K = C contractions (operand loads issued KU steps ahead)
 
 struct Smem {
@@ -101,70 +93,75 @@ __device__ __forceinline__ Smem carve(float* base, int C, int P) {
   return s;
 }
 
-// HBM -> registers (issue only) and registers -> LDS of one [C][P] tile (count % 4 == 0, 16-B aligned).
-// Seven NAMED float4 per thread (an indexed array ends up in scratch memory, which turns the prefetch into a
-// synchronous round trip through HBM).  Loads are unconditional on a clamped index; the commit is guarded.
-#if PIXPRO_NW == 16     // 1024 threads: 4 float4 per thread cover 16,384 floats
-#define PF_DECL(p) float4 p##0, p##1, p##2, p##3
-#define PF_ISSUE(p, src, count)                                                    \
-  do {                                                                             \
-    const float4* s4_ = reinterpret_cast<const float4*>(src);                      \
-    const int n4_ = (count) / 4 - 1, t_ = threadIdx.x;                             \
-    p##0 = s4_[min(t_, n4_)];                 p##1 = s4_[min(t_ + NTHREADS, n4_)];     \
-    p##2 = s4_[min(t_ + 2 * NTHREADS, n4_)];  p##3 = s4_[min(t_ + 3 * NTHREADS, n4_)]; \
-  } while (0)
-#define PF_COMMIT(p, dst, count)                                                   \
-  do {                                                                             \
-    float4* d4_ = reinterpret_cast<float4*>(dst);                                  \
-    const int n4_ = (count) / 4, t_ = threadIdx.x;                                 \
-    if (t_ < n4_) d4_[t_] = p##0;                                                  \
-    if (t_ + NTHREADS < n4_) d4_[t_ + NTHREADS] = p##1;                            \
-    if (t_ + 2 * NTHREADS < n4_) d4_[t_ + 2 * NTHREADS] = p##2;                    \
-    if (t_ + 3 * NTHREADS < n4_) d4_[t_ + 3 * NTHREADS] = p##3;                    \
-  } while (0)
-#else
+// HBM -> registers (issue only) and registers -> LDS of one [C][P] tile (count % 4 == 0, 16-B aligned), executed by
+// the 448 threads of waves 1..7.  Seven NAMED float4 per thread (an indexed array ends up in scratch memory, which turns
+// the prefetch into a synchronous round trip through HBM).  Loads are unconditional on a clamped index; the commit is
+// guarded.
 #define PF_DECL(p) float4 p##0, p##1, p##2, p##3, p##4, p##5, p##6
 #define PF_ISSUE(p, src, count)                                                    \
   do {                                                                             \
     const float4* s4_ = reinterpret_cast<const float4*>(src);                      \
-    const int n4_ = (count) / 4 - 1, t_ = threadIdx.x;                             \
-    p##0 = s4_[min(t_, n4_)];                 p##1 = s4_[min(t_ + NTHREADS, n4_)];     \
-    p##2 = s4_[min(t_ + 2 * NTHREADS, n4_)];  p##3 = s4_[min(t_ + 3 * NTHREADS, n4_)]; \
-    p##4 = s4_[min(t_ + 4 * NTHREADS, n4_)];  p##5 = s4_[min(t_ + 5 * NTHREADS, n4_)]; \
-    p##6 = s4_[min(t_ + 6 * NTHREADS, n4_)];                                       \
+    const int n4_ = (count) / 4 - 1, t_ = (int)threadIdx.x - WAVE;                 \
+    p##0 = s4_[min(t_, n4_)];              p##1 = s4_[min(t_ + NLOAD, n4_)];       \
+    p##2 = s4_[min(t_ + 2 * NLOAD, n4_)];  p##3 = s4_[min(t_ + 3 * NLOAD, n4_)];   \
+    p##4 = s4_[min(t_ + 4 * NLOAD, n4_)];  p##5 = s4_[min(t_ + 5 * NLOAD, n4_)];   \
+    p##6 = s4_[min(t_ + 6 * NLOAD, n4_)];                                          \
   } while (0)
 #define PF_COMMIT(p, dst, count)                                                   \
   do {                                                                             \
     float4* d4_ = reinterpret_cast<float4*>(dst);                                  \
-    const int n4_ = (count) / 4, t_ = threadIdx.x;                                 \
+    const int n4_ = (count) / 4, t_ = (int)threadIdx.x - WAVE;                     \
     if (t_ < n4_) d4_[t_] = p##0;                                                  \
-    if (t_ + NTHREADS < n4_) d4_[t_ + NTHREADS] = p##1;                            \
-    if (t_ + 2 * NTHREADS < n4_) d4_[t_ + 2 * NTHREADS] = p##2;                    \
-    if (t_ + 3 * NTHREADS < n4_) d4_[t_ + 3 * NTHREADS] = p##3;                    \
-    if (t_ + 4 * NTHREADS < n4_) d4_[t_ + 4 * NTHREADS] = p##4;                    \
-    if (t_ + 5 * NTHREADS < n4_) d4_[t_ + 5 * NTHREADS] = p##5;                    \
-    if (t_ + 6 * NTHREADS < n4_) d4_[t_ + 6 * NTHREADS] = p##6;                    \
+    if (t_ + NLOAD < n4_) d4_[t_ + NLOAD] = p##1;                                  \
+    if (t_ + 2 * NLOAD < n4_) d4_[t_ + 2 * NLOAD] = p##2;                          \
+    if (t_ + 3 * NLOAD < n4_) d4_[t_ + 3 * NLOAD] = p##3;                          \
+    if (t_ + 4 * NLOAD < n4_) d4_[t_ + 4 * NLOAD] = p##4;                          \
+    if (t_ + 5 * NLOAD < n4_) d4_[t_ + 5 * NLOAD] = p##5;                          \
+    if (t_ + 6 * NLOAD < n4_) d4_[t_ + 6 * NLOAD] = p##6;                          \
   } while (0)
-#endif
-// NHWC (channels_last) tiles: the sample is [P][C] in HBM.  A wave covers 8 pixels x 8 groups of 4 channels per
-// row-block (8 x 128-B segments per load / store instruction) and transposes through scalar LDS accesses into /
-// out of the same [C][P] LDS image the NCHW path uses.  8-wave build only; PF row-blocks of 8 pixels cover P <= 56.
-#if PIXPRO_NW == 8
+// NHWC (channels_last) tiles: the sample is [P][C] in HBM.  One wave-load covers 4 pixels x 16 groups of 4 channels
+// (4 x 256-B segments); the 4 x 64 scalar LDS writes that transpose it into the [C][P] image the NCHW path uses fall
+// into 64 different banks (word address (4 c4 + q) P + p, P odd).  Loads are numbered L = (wave - 1) + 7 i: first the
+// (P / 4) x (C4 / 16) full ones, then one per left-over pixel (a whole row of C4 <= 64 groups); 49 loads cover
+// 49 x 256 exactly.
+struct NhwcSlot {
+  int p, c4;
+  bool ok;
+};
+__device__ __forceinline__ NhwcSlot nhwc_slot(int i, int C4, int P) {
+  const int wave = (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int L = (wave - 1) + (NWAVES - 1) * i;
+  const int CG = C4 >> 4, full = (P >> 2) * CG;
+  NhwcSlot s;
+  if (L < full) {
+    s.p = 4 * (L / CG) + (lane >> 4);
+    s.c4 = 16 * (L % CG) + (lane & 15);
+    s.ok = true;
+  } else {
+    s.p = (P & ~3) + (L - full);
+    s.c4 = lane;
+    s.ok = s.p < P && lane < C4;
+  }
+  return s;
+}
+#define PFT_GET_(v, i, s4, C4, P)                                                         \
+  do {                                                                                    \
+    const NhwcSlot s_ = nhwc_slot(i, C4, P);                                              \
+    v = (s4)[min(s_.p, (P) - 1) * (C4) + min(s_.c4, (C4) - 1)];                           \
+  } while (0)
 #define PFT_ISSUE(p, src, C4, P)                                                          \
   do {                                                                                    \
     const float4* s4_ = reinterpret_cast<const float4*>(src);                             \
-    const int ps_ = threadIdx.x & 7, c4_ = min((int)(threadIdx.x >> 3), (C4) - 1);        \
-    p##0 = s4_[min(ps_, (P) - 1) * (C4) + c4_];       p##1 = s4_[min(8 + ps_, (P) - 1) * (C4) + c4_];  \
-    p##2 = s4_[min(16 + ps_, (P) - 1) * (C4) + c4_];  p##3 = s4_[min(24 + ps_, (P) - 1) * (C4) + c4_]; \
-    p##4 = s4_[min(32 + ps_, (P) - 1) * (C4) + c4_];  p##5 = s4_[min(40 + ps_, (P) - 1) * (C4) + c4_]; \
-    p##6 = s4_[min(48 + ps_, (P) - 1) * (C4) + c4_];                                      \
+    PFT_GET_(p##0, 0, s4_, C4, P); PFT_GET_(p##1, 1, s4_, C4, P); PFT_GET_(p##2, 2, s4_, C4, P); \
+    PFT_GET_(p##3, 3, s4_, C4, P); PFT_GET_(p##4, 4, s4_, C4, P); PFT_GET_(p##5, 5, s4_, C4, P); \
+    PFT_GET_(p##6, 6, s4_, C4, P);                                                        \
   } while (0)
-#define PFT_PUT_(v, blk, dst, C4, P)                                                      \
+#define PFT_PUT_(v, i, dst, C4, P)                                                        \
   do {                                                                                    \
-    const int p_ = (blk) * 8 + (threadIdx.x & 7), c_ = 4 * (int)(threadIdx.x >> 3);       \
-    if (p_ < (P) && c_ < 4 * (C4)) {                                                      \
-      (dst)[c_ * (P) + p_] = v.x; (dst)[(c_ + 1) * (P) + p_] = v.y;                       \
-      (dst)[(c_ + 2) * (P) + p_] = v.z; (dst)[(c_ + 3) * (P) + p_] = v.w;                 \
+    const NhwcSlot s_ = nhwc_slot(i, C4, P);                                              \
+    if (s_.ok) {                                                                          \
+      float* d_ = (dst) + 4 * s_.c4 * (P) + s_.p;                                         \
+      d_[0] = v.x; d_[P] = v.y; d_[2 * (P)] = v.z; d_[3 * (P)] = v.w;                     \
     }                                                                                     \
   } while (0)
 #define PFT_COMMIT(p, dst, C4, P)                                                         \
@@ -184,7 +181,6 @@ __device__ __forceinline__ void store_tile_nhwc(float* __restrict__ dst, const f
           make_float4(src[c * P + p], src[(c + 1) * P + p], src[(c + 2) * P + p], src[(c + 3) * P + p]);
   }
 }
-#endif
 
 __device__ __forceinline__ void store_tile(float* __restrict__ dst, const float* __restrict__ src, int count) {
   for (int e = threadIdx.x * 4; e < count; e += NTHREADS * 4)
@@ -331,6 +327,28 @@ __device__ __forceinline__ void gemm_pp(f32x4& acc0, f32x4& acc1, const float* _
 __device__ __forceinline__ float dist_threshold(float diag, float r, int lane) {
   if (!(r == r) || !(diag > 0.f)) return 0.f;          // NaN ratio, zero / NaN diagonal: nothing passes
   long long lo = -1, hi = 0x7f800000LL + 1;            // test(lo) passes (or lo = -1); test(hi) fails (or hi = sentinel)
+  {
+    // One round usually settles it: T is within a few ulps of (r diag)^2, so test the 64 neighbouring bit patterns and
+    // keep the bracket they prove (pattern c0 passes and c0 + k fails  =>  lo = c0 + k - 1, hi = c0 + k).
+    const float t0 = (r * diag) * (r * diag);
+    if (t0 > 0.f && t0 < 3.0e38f) {
+      const long long c0 = (long long)__float_as_uint(t0) - 32;
+      const long long c = c0 + lane;
+      const bool in = c >= 0 && c <= 0x7f800000LL;
+      bool fails = true;
+      if (in) fails = (sqrtf(__uint_as_float((unsigned)c)) / diag) >= r;
+      const unsigned long long m = __ballot(fails);
+      const unsigned long long inm = __ballot(in);
+      if (inm == ~0ull && !(m & 1ull) && m != 0) {      // first pattern passes, a later one fails
+        const int first = __ffsll((long long)m) - 1;
+        lo = c0 + first - 1; hi = c0 + first;
+      } else if (inm == ~0ull && m == 0) {
+        lo = c0 + 63;                                   // all pass: the search below continues above the window
+      } else if (inm == ~0ull && (m & 1ull)) {
+        hi = c0;                                        // all fail (monotone): continues below the window
+      }
+    }
+  }
   while (hi - lo > 1) {
     const long long step = (hi - lo - 1 + 63) / 64;
     const long long c = lo + (long long)(lane + 1) * step;
@@ -373,23 +391,16 @@ ppm_fused_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* _
   auto crow = [&](int m, int r) { return 16 * (wave + NWAVES * m) + 4 * lq + r; };
 
   STAMP(0);
-  // ---- x -> B0 and v -> B1 in flight together; bin centres / flow taps meanwhile ----
+  // ---- waves 1..7: x -> B0 and v -> B1 in flight together; wave 0: bin centres, flow taps, threshold ----
   PF_DECL(pfa);
   PF_DECL(pfb);
-#if PIXPRO_NW == 8
   const bool nhwc = pb.layout == 1;
   const int C4 = C / 4;
-#define LOAD_TILE(p, src)  do { if (nhwc) PFT_ISSUE(p, src, C4, P); else PF_ISSUE(p, src, tile); } while (0)
-#define PUT_TILE(p, dst)   do { if (nhwc) PFT_COMMIT(p, dst, C4, P); else PF_COMMIT(p, dst, tile); } while (0)
+#define LOAD_TILE(p, src)  do { if (wave != 0) { if (nhwc) PFT_ISSUE(p, src, C4, P); else PF_ISSUE(p, src, tile); } } while (0)
+#define PUT_TILE(p, dst)   do { if (wave != 0) { if (nhwc) PFT_COMMIT(p, dst, C4, P); else PF_COMMIT(p, dst, tile); } } while (0)
 #define OUT_TILE(gdst, src) do { if (nhwc) store_tile_nhwc(gdst, src, C4, P); else store_tile(gdst, src, tile); } while (0)
-#else
-  const bool nhwc = false;
-#define LOAD_TILE(p, src)  PF_ISSUE(p, src, tile)
-#define PUT_TILE(p, dst)   PF_COMMIT(p, dst, tile)
-#define OUT_TILE(gdst, src) store_tile(gdst, src, tile)
-#endif
-  LOAD_TILE(pfa, gx);
-  LOAD_TILE(pfb, gv);
+  LOAD_TILE(pfa, gx);               // x alone first: with v queued behind it as well, wave 0's nine tap loads below would
+                                    // sit behind 100 KB in the CU's memory queue (measured: 9 k cycles to issue them)
   if (tid < 4) { sm.B0[tile + tid] = 0.f; sm.B1[tile + tid] = 0.f; }
   // lazy flow mode with a chain (nframe > 2): the nine composed-flow pixels each point needs (common.h) are spread over
   // the work-group, two dependent stages through LDS (the AA matrix is not live yet), so that a point costs two chain
@@ -421,78 +432,50 @@ ppm_fused_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* _
     }
     __syncthreads();
   }
-  if (tid < 64) {
-    float qx = 0.f, qy = 0.f, kx = 0.f, ky = 0.f;
-    int valid = 0;
-    if (tid < P) {
-      int Ho, Wo;
-      frame_size(pb, dd, Ho, Wo);
-      const float wo1 = (float)(Wo - 1), ho1 = (float)(Ho - 1);
-      const Crop cq = crop_of(dd.coord_q + (size_t)n * 10, pb.H, pb.W);
-      const Crop ck = crop_of(dd.coord_k + (size_t)n * 10, pb.H, pb.W);
-      const int row = tid / pb.W, col = tid % pb.W;
-      qx = centre_x(cq, col, wo1); qy = centre_y(cq, row, ho1);
-      kx = centre_x(ck, col, wo1); ky = centre_y(ck, row, ho1);
-      bool v = true;
-      if (dd.lo_own) {          // lazy flow mode: evaluate flow + validity at this point from the low-res maps
-        const FlowGeom fg = flow_geom(8 * pb.lo_h, 8 * pb.lo_w, Ho, Wo);
-        const LazySrc ls = lazy_src(pb, dd, n);
-        float ox, oy;
-        if (lazy_spread) lazy_finish(ls, fg, lazy_point(fg, qx, qy), qx, qy, sm.AA + 10 * tid, sm.AA + 10 * P + 8 * tid, ox, oy, v);
-        else displace_point_lazy(ls, fg, qx, qy, ox, oy, v);
-        qx = ox; qy = oy;
-      } else if (dd.flow) {
-        const FlowGeom fg = flow_geom(pb.Hf, pb.Wf, Ho, Wo);
-        float ox, oy;
-        displace_point(dd.flow + (size_t)n * 2 * pb.Hf * pb.Wf,
-                       dd.mask ? dd.mask + (size_t)n * pb.Hf * pb.Wf : nullptr, fg, qx, qy, ox, oy, v);
-        qx = ox; qy = oy;
-      }
-      valid = v ? 1 : 0;
-    }
-    sm.qx[tid] = qx; sm.qy[tid] = qy; sm.kx[tid] = kx; sm.ky[tid] = ky; sm.valid[tid] = valid;
-  }
-  if (wave == 1) {                  // threshold of the positive-pair test (needs only the two crop records)
+  // Wave 0 has no tile loads of its own queued in front of these: the crop records come through the scalar cache, the
+  // dense-flow taps are ONE vector round trip (displace_fetch) whose results are only consumed after the S contraction,
+  // and the threshold search runs while they are in flight.  (Before: 12-16 k cycles in front of the first barrier -
+  // five dependent round trips queued behind the wave's own tile loads.)
+  float ptx = 0.f, pty = 0.f, pkx = 0.f, pky = 0.f;
+  bool ptv = true, dense = false;
+  PointTaps taps;      // written and read by wave 0 in dense mode only; NOT zero-initialised: merging a zero with the loaded
+  FlowGeom fgd;        // values at the end of the branch would make the compiler wait for the loads right there
+  if (wave == 0) {
     int Ho, Wo;
-    frame_size(pb, dd, Ho, Wo);
+    frame_size_uniform(pb, dd, Ho, Wo);
     const float wo1 = (float)(Wo - 1), ho1 = (float)(Ho - 1);
-    const float diag = fmaxf(bin_diag(crop_of(dd.coord_q + (size_t)n * 10, pb.H, pb.W), wo1, ho1),
-                             bin_diag(crop_of(dd.coord_k + (size_t)n * 10, pb.H, pb.W), wo1, ho1));
-    const float T = dist_threshold(diag, pb.pos_ratio, lane);
+    const Crop cq = crop_of_uniform(dd.coord_q + (size_t)n * 10, pb.H, pb.W);
+    const Crop ck = crop_of_uniform(dd.coord_k + (size_t)n * 10, pb.H, pb.W);
+    const int pt = min(lane, P - 1), row = pt / pb.W, col = pt % pb.W;
+    ptx = centre_x(cq, col, wo1); pty = centre_y(cq, row, ho1);
+    pkx = centre_x(ck, col, wo1); pky = centre_y(ck, row, ho1);
+    dense = dd.lo_own == nullptr && dd.flow != nullptr;
+    if (dense) {
+      fgd = flow_geom(pb.Hf, pb.Wf, Ho, Wo);
+      taps = displace_fetch(dd.flow + (size_t)n * 2 * pb.Hf * pb.Wf,
+                            dd.mask ? dd.mask + (size_t)n * pb.Hf * pb.Wf : nullptr, fgd, ptx, pty);
+    }
+    STAMP(17);
+    // threshold of the positive-pair test (needs only the two crop records)
+    const float T = dist_threshold(fmaxf(bin_diag(cq, wo1, ho1), bin_diag(ck, wo1, ho1)), pb.pos_ratio, lane);
     if (lane == 0) sm.misc[2] = T;
+    if (dd.lo_own) {            // lazy flow mode: evaluate flow + validity at this point from the low-res maps
+      const FlowGeom fg = flow_geom(8 * pb.lo_h, 8 * pb.lo_w, Ho, Wo);
+      const LazySrc ls = lazy_src(pb, dd, n);
+      float ox, oy;
+      if (lazy_spread) lazy_finish(ls, fg, lazy_point(fg, ptx, pty), ptx, pty, sm.AA + 10 * pt, sm.AA + 10 * P + 8 * pt, ox, oy, ptv);
+      else displace_point_lazy(ls, fg, ptx, pty, ox, oy, ptv);
+      ptx = ox; pty = oy;
+    }
   }
+  STAMP(16);
   PUT_TILE(pfa, sm.B0);
-  PUT_TILE(pfb, sm.B1);
-  LOAD_TILE(pfa, gk);               // k streams in under the mask / norm / S phases
   __syncthreads();
   STAMP(1);
-
-  // ---- positive-pair bit mask: row i of M = ballot over j (PixPro.py:217-223) ----
-  {
-    const float T = sm.misc[2];     // sqrtf(d2) / diag < pos_ratio  <=>  d2 < T  (dist_threshold)
-    const float kxj = sm.kx[lane], kyj = sm.ky[lane];
-    int cnt_w = 0;
-    for (int i = wave; i < 64; i += NWAVES) {
-      bool pred = false;
-      if (i < P && lane < P) {
-        const float dx = sm.qx[i] - kxj, dy = sm.qy[i] - kyj;
-        pred = (dx * dx + dy * dy < T) && (sm.valid[i] != 0);
-      }
-      const unsigned long long bits = __ballot(pred);
-      if (lane == 0) sm.mbits[i] = bits;
-      cnt_w += __popcll(bits);
-    }
-    if (lane == 0) sm.misc[8 + wave] = (float)cnt_w;
-  }
-  __syncthreads();
-  if (tid == 0) {
-    float c = 0.f;
-    for (int w = 0; w < NWAVES; ++w) c += sm.misc[8 + w];
-    sm.misc[1] = c;
-  }
-  STAMP(2);
-  col_rnorms(sm.B1, sm.rv, sm.part0, C, P);           // (barriers inside also publish misc[1])
-  STAMP(3);
+  // One tile request at a time: the CU's memory queue holds about one tile's worth of wave-loads; with more, a wave
+  // stalls at the *issue* of its next load until the queue drains (measured: 14 loads per wave took 5.9 k cycles to
+  // issue), and a barrier behind such a stall costs every wave that time.
+  LOAD_TILE(pfb, gv);               // v streams in under the S contraction
 
   // ---- S_raw = x^T x ; rx from its diagonal ; S, A, D ----
   {
@@ -508,9 +491,48 @@ ppm_fused_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* _
           if (4 * lq + r == lr) sm.nx2[16 * (tt / NT) + lr] = acc[r];
       }
     }
+    if (wave == 0) {                 // the sample points: taps requested before the contraction
+      if (dense) {
+        float ox, oy;
+        displace_finish(taps, fgd, ptx, pty, ox, oy, ptv);
+        ptx = ox; pty = oy;
+      }
+      const bool live = lane < P;
+      sm.qx[lane] = live ? ptx : 0.f; sm.qy[lane] = live ? pty : 0.f;
+      sm.kx[lane] = live ? pkx : 0.f; sm.ky[lane] = live ? pky : 0.f;
+      sm.valid[lane] = (live && ptv) ? 1 : 0;
+    }
+    PUT_TILE(pfb, sm.B1);            // v has had the S contraction to arrive
+    LOAD_TILE(pfa, gk);              // k streams in under the mask / norm / S epilogue phases
     __syncthreads();
+    STAMP(2);
     if (tid < 64) sm.rx[tid] = 1.f / fmaxf(sqrtf(sm.nx2[tid < 16 * NT ? tid : 0]), 1e-12f);
-    __syncthreads();
+    // ---- positive-pair bit mask: row i of M = ballot over j (PixPro.py:217-223); row i's point comes out of lane i ----
+    {
+      const float T = sm.misc[2];     // sqrtf(d2) / diag < pos_ratio  <=>  d2 < T  (dist_threshold)
+      const float kxj = sm.kx[lane], kyj = sm.ky[lane], qxl = sm.qx[lane], qyl = sm.qy[lane];
+      const unsigned long long vrows = __ballot(sm.valid[lane] != 0);
+      int cnt_w = 0;
+#pragma unroll
+      for (int it = 0; it < 64 / NWAVES; ++it) {
+        const int i = wave + NWAVES * it;
+        const float qxi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qxl), i));
+        const float qyi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qyl), i));
+        const float dx = qxi - kxj, dy = qyi - kyj;
+        const bool pred = i < P && lane < P && (dx * dx + dy * dy < T) && ((vrows >> i) & 1ull);
+        const unsigned long long bits = __ballot(pred);
+        if (lane == 0) sm.mbits[i] = bits;
+        cnt_w += __popcll(bits);
+      }
+      if (lane == 0) sm.misc[8 + wave] = (float)cnt_w;
+    }
+    STAMP(3);
+    col_rnorms(sm.B1, sm.rv, sm.part0, C, P);           // (barriers inside also publish rx, the mask rows and counts)
+    if (tid == 0) {
+      float c = 0.f;
+      for (int w = 0; w < NWAVES; ++w) c += sm.misc[8 + w];
+      sm.misc[1] = c;                                    // read in the loss phase, several barriers from here
+    }
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int tt = wave + NWAVES * t;
@@ -806,22 +828,22 @@ int launch(const pixpro_problem& pb, const Dirs& D, float* loss_n, float* pos_nu
 
 }  // namespace
 
-bool WFN(fused_supported)(const pixpro_problem& pb) {
+bool fused_supported(const pixpro_problem& pb) {
   const int P = pb.H * pb.W;
   if (P > 64 || P < 1) return false;
-  if (pb.C != 16 * NWAVES && !(NWAVES == 8 && pb.C == 256)) return false;
-  if ((size_t)pb.C * P > (size_t)PF * NTHREADS * 4) return false;
-  if (pb.layout == 1 && (NWAVES != 8 || P > 56)) return false;
+  if (pb.C != 128 && pb.C != 256) return false;
+  if ((size_t)pb.C * P > (size_t)PF * NLOAD * 4) return false;      // 7 loader waves x 7 float4: P <= 49 at C = 256
+  if (pb.layout == 1 && (P / 4) * (pb.C / 64) + P % 4 > PF * (NWAVES - 1)) return false;   // NHWC wave-loads (nhwc_slot)
   return smem_floats(pb.C, P) * sizeof(float) <= 160 * 1024;
 }
 
-int WFN(run_fused)(const pixpro_problem& pb, const pixpro_dir* dirs, float* loss_n, float* pos_num, float* pos_mean,
+int run_fused(const pixpro_problem& pb, const pixpro_dir* dirs, float* loss_n, float* pos_num, float* pos_mean,
                    hipStream_t st) {
   Dirs D;
   for (int d = 0; d < PIXPRO_MAX_DIRS; ++d) D.d[d] = dirs[d < pb.ndir ? d : 0];
   const int P = pb.H * pb.W;
   const int NT = (P + 15) / 16;
-  if (pb.C == 32 * NWAVES) {   // two C-tiles per wave (8 waves, C = 256)
+  if (pb.C == 32 * NWAVES) {   // two C-tiles per wave (C = 256)
     if (P == 49) return launch<2, 4, 49>(pb, D, loss_n, pos_num, pos_mean, st);
     switch (NT) {
       case 1: return launch<2, 1>(pb, D, loss_n, pos_num, pos_mean, st);

@@ -33,8 +33,13 @@ def main():
     ap.add_argument("--flow-offset", type=float, default=0.0, help="constant added to the forward flow's x component (full-res "
                                                                     "pixels; the backward flow gets the negative): coherent motion")
     ap.add_argument("--flow-step", type=float, default=0.0, help="motion boundary: this many pixels added right of the middle")
+    ap.add_argument("--lib", default=None, help="load this build of libpixpro_hip.so instead of the in-tree one (kernel variants)")
+    ap.add_argument("--channels-last", action="store_true", help="feature maps in channels_last memory format (bench default)")
     a = ap.parse_args()
     import types
+    if a.lib:
+        from contrast import _native
+        _native.LIB_PATH = os.path.abspath(a.lib)
     from contrast import ops, util
     from contrast.synthetic import make_batch
     dev = torch.device("cuda:0")
@@ -59,7 +64,8 @@ def main():
                                    unfused_equiv_GBps=(2 * F1 * 2 * A / 64 + 8 * F1 * A + 4.5 * A) * N / med / 1e6)
     C, P = 256, G * G
     gen = torch.Generator(device=dev).manual_seed(0)
-    t = lambda: torch.randn(N, C, G, G, device=dev, generator=gen)
+    mf = torch.channels_last if a.channels_last else torch.contiguous_format
+    t = lambda: torch.randn(N, C, G, G, device=dev, generator=gen).contiguous(memory_format=mf)
     x1, v1, x2, v2, k1, k2 = (t() for _ in range(6))
     x1.requires_grad_(True); v1.requires_grad_(True); x2.requires_grad_(True); v2.requires_grad_(True)
     size = (720, 1280)

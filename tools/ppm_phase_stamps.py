@@ -11,13 +11,13 @@ PKG = os.path.join(ROOT, "pixpro-with-opticalflow_amd")
 sys.path.insert(0, PKG)
 import torch  # noqa: E402
 
-NAMES = ["start", "load x,v + pts", "maskbits", "rv norms", "S gemm+epi", "Y gemm", "ny, rk, Yhat", "G gemm", "loss",
+NAMES = ["start", "load x, tap issue", "S gemm, pts, v->LDS", "rx, maskbits", "rv norms, S epi", "Y gemm", "ny, rk, Yhat", "G gemm", "loss",
          "dY", "dA gemm+epi", "symm", "dV gemm+epi", "store dv", "dX gemm+epi", "store dx"]
 
 
 def main():
     out = "/tmp/libpixpro_hip_stamps.so"
-    srcs = [os.path.join(PKG, "csrc", f) for f in ("capi.hip", "ppm_fused.hip", "ppm_generic.hip", "flow_prep.hip",
+    srcs = [os.path.join(PKG, "csrc", f) for f in ("capi.hip", "ppm_fused.hip", "ppm_generic.hip", "ppm_tiled.hip", "flow_prep.hip",
                                                    "multi_tensor.hip", "sync_bn.hip", "raft_corr.hip")]
     objs = []
     base = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off",
@@ -26,9 +26,8 @@ def main():
         o = "/tmp/stamps_" + os.path.basename(src) + ".o"
         subprocess.run(base + ["-c", src, "-o", o], check=True)
         objs.append(o)
-    subprocess.run(base + ["-DPIXPRO_NW=16", "-c", srcs[1], "-o", "/tmp/stamps_w16.o"], check=True)
     subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-fgpu-rdc", "--hip-link", "-shared", "-fPIC", "-o", out]
-                   + objs + ["/tmp/stamps_w16.o"], check=True)
+                   + objs, check=True)
     from contrast import _native
     _native.LIB_PATH = out
     from contrast import ops
@@ -57,6 +56,8 @@ def main():
     print(f"total ticks {tot} (s_memtime, 100 MHz const clock? -> {tot / 100:.1f} us if so)")
     for i in range(1, 16):
         print(f"{NAMES[i]:>16s} {st[i] - st[i - 1]:8d} {100.0 * (st[i] - st[i - 1]) / tot:5.1f}%")
+    extra = list(buf)[16:24]
+    print("extra stamps relative to start:", [e - st[0] if e else None for e in extra])
 
 
 if __name__ == "__main__":
