@@ -320,6 +320,41 @@ __device__ __forceinline__ void gemm_pp(f32x4& acc0, f32x4& acc1, const float* _
   }
 }
 
+// One 16 x 16 tile (ti, tj) of L^T R over K = C, two interleaved accumulators (even / odd k-steps) so that
+// consecutive MFMAs never wait on each other's result; returns their sum.  Same double buffering as gemm_pp.
+__device__ __forceinline__ f32x4 gemm_pp_tile(const float* __restrict__ L, const float* __restrict__ R, int C, int P,
+                                              int ti, int tj) {
+  const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
+  const float* la = L + lq * P + min(16 * ti + lr, P - 1);
+  const float* rb = R + lq * P + min(16 * tj + lr, P - 1);
+  const int step = 4 * P;
+  const int nblk = C / 4 / KU;
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  float a[KU], b[KU];
+#pragma unroll
+  for (int u = 0; u < KU; ++u) { a[u] = la[u * step]; b[u] = rb[u * step]; }
+  for (int blk = 0; blk < nblk; ++blk) {
+    float an[KU], bn[KU];
+    const int adv = blk + 1 < nblk ? KU * step : 0;     // the last block re-reads itself (never used)
+    la += adv; rb += adv;
+#pragma unroll
+    for (int u = 0; u < KU; ++u) { an[u] = la[u * step]; bn[u] = rb[u * step]; }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < KU; u += 2) {
+      acc0 = mfma16(a[u], b[u], acc0);
+      acc1 = mfma16(a[u + 1], b[u + 1], acc1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < KU; ++u) { a[u] = an[u]; b[u] = bn[u]; }
+  }
+  f32x4 acc;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc[r] = acc0[r] + acc1[r];
+  return acc;
+}
+
 // Positive-pair test `sqrtf(d2) / diag < r` (PixPro.py:217-219) as `d2 < T`: correctly rounded sqrt and division are
 // monotone, so the set of d2 that pass is a down-set of the non-negative floats; T is its supremum, found by a 64-ary
 // search over the bit patterns (6 rounds of one sqrt + one division per lane, run by one wave while the tiles are in
@@ -478,17 +513,44 @@ ppm_fused_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* _
   LOAD_TILE(pfb, gv);               // v streams in under the S contraction
 
   // ---- S_raw = x^T x ; rx from its diagonal ; S, A, D ----
+  // 7 x 7 grid (PC == 49): S is symmetric and 49 = 48 + 1, so only the six upper tiles of the 3 x 3 tile grid go to the
+  // matrix cores - one per wave 0..5, 64 MFMAs instead of the 128 of two tiles of the padded 4 x 4 grid - and are
+  // mirrored by the epilogue; waves 6 and 7, which share their SIMDs with one MFMA wave each, take row 48
+  // (49 dot products over half of C each) on the vector ALU.
+  constexpr bool SYM = PC == 49;
   {
     f32x4 acc0 = zero4, acc1 = zero4;
-    gemm_pp<NT>(acc0, acc1, sm.B0, sm.B0, C, P);
+    const int sti = (wave >= 3) + (wave >= 5), stj = wave - (wave >= 3 ? 2 : 0) - (wave >= 5 ? 1 : 0);   // SYM: tile of waves 0..5
+    if constexpr (SYM) {
+      if (wave < 6) {
+        acc0 = gemm_pp_tile(sm.B0, sm.B0, C, P, sti, stj);
+        if (sti == stj) {
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int tt = wave + NWAVES * t;
-      if (tt < NT * NT && tt / NT == tt % NT) {
-        const f32x4& acc = t ? acc1 : acc0;
+          for (int r = 0; r < 4; ++r)
+            if (4 * lq + r == lr) sm.nx2[16 * sti + lr] = acc0[r];
+        }
+      } else {
+        const int half = C / 2, jj = min(lane, P - 1);
+        const float* xe = sm.B0 + (wave - 6) * half * P;
+        float e0 = 0.f, e1 = 0.f;
+#pragma unroll 8
+        for (int c = 0; c < half; c += 2) {
+          e0 = __builtin_fmaf(xe[c * P + (P - 1)], xe[c * P + jj], e0);
+          e1 = __builtin_fmaf(xe[(c + 1) * P + (P - 1)], xe[(c + 1) * P + jj], e1);
+        }
+        sm.part1[(wave - 6) * 64 + lane] = e0 + e1;       // part1 is next used by the Y-norm reduction
+      }
+    } else {
+      gemm_pp<NT>(acc0, acc1, sm.B0, sm.B0, C, P);
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (4 * lq + r == lr) sm.nx2[16 * (tt / NT) + lr] = acc[r];
+      for (int t = 0; t < 2; ++t) {
+        const int tt = wave + NWAVES * t;
+        if (tt < NT * NT && tt / NT == tt % NT) {
+          const f32x4& acc = t ? acc1 : acc0;
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (4 * lq + r == lr) sm.nx2[16 * (tt / NT) + lr] = acc[r];
+        }
       }
     }
     if (wave == 0) {                 // the sample points: taps requested before the contraction
@@ -506,7 +568,11 @@ ppm_fused_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* _
     LOAD_TILE(pfa, gk);              // k streams in under the mask / norm / S epilogue phases
     __syncthreads();
     STAMP(2);
-    if (tid < 64) sm.rx[tid] = 1.f / fmaxf(sqrtf(sm.nx2[tid < 16 * NT ? tid : 0]), 1e-12f);
+    if (tid < 64) {
+      float n2 = sm.nx2[tid < 16 * NT ? tid : 0];
+      if (SYM && tid >= 48) n2 = sm.part1[48] + sm.part1[64 + 48];
+      sm.rx[tid] = 1.f / fmaxf(sqrtf(n2), 1e-12f);
+    }
     // ---- positive-pair bit mask: row i of M = ballot over j (PixPro.py:217-223); row i's point comes out of lane i ----
     {
       const float T = sm.misc[2];     // sqrtf(d2) / diag < pos_ratio  <=>  d2 < T  (dist_threshold)
@@ -533,21 +599,54 @@ ppm_fused_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* _
       for (int w = 0; w < NWAVES; ++w) c += sm.misc[8 + w];
       sm.misc[1] = c;                                    // read in the loss phase, several barriers from here
     }
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int tt = wave + NWAVES * t;
-      if (tt < NT * NT) {
-        const f32x4& acc = t ? acc1 : acc0;
-        const int mi = tt / NT, nj = tt % NT, j = 16 * nj + lr;
+    if constexpr (SYM) {
+      if (wave < 6) {
+        const int j = 16 * stj + lr;
         const float rxj = sm.rx[j];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int i = 16 * mi + 4 * lq + r;
-          if (i < LR) {
-            float a = 0.f, d = 0.f;
-            if (i < P && j < P) pow_map(acc[r] * sm.rx[i] * rxj, pb.p, pb.clamp, a, d);
-            sm.AA[i * LS + j] = a;
-            sm.Dm[i * LS + j] = d;
+          const int i = 16 * sti + 4 * lq + r;
+          float a, d;
+          pow_map(acc0[r] * sm.rx[i] * rxj, pb.p, pb.clamp, a, d);
+          sm.AA[i * LS + j] = a;
+          sm.Dm[i * LS + j] = d;
+          if (sti != stj) { sm.AA[j * LS + i] = a; sm.Dm[j * LS + i] = d; }
+        }
+      } else {
+        // row / column 48, then the zero padding the contractions read: rows 49..51 and columns 49..63
+        const int t2 = tid - 6 * WAVE;                    // 0..127
+        if (t2 < P) {
+          float a, d;
+          pow_map((sm.part1[t2] + sm.part1[64 + t2]) * sm.rx[P - 1] * sm.rx[t2], pb.p, pb.clamp, a, d);
+          sm.AA[(P - 1) * LS + t2] = a; sm.Dm[(P - 1) * LS + t2] = d;
+          sm.AA[t2 * LS + (P - 1)] = a; sm.Dm[t2 * LS + (P - 1)] = d;
+        }
+        for (int e = t2; e < (LR - P) * 64; e += 2 * WAVE) {
+          const int i = P + (e >> 6), jz = e & 63;
+          sm.AA[i * LS + jz] = 0.f; sm.Dm[i * LS + jz] = 0.f;
+        }
+        for (int e = t2; e < P * (64 - P); e += 2 * WAVE) {
+          const int i = e / (64 - P), jz = P + e % (64 - P);
+          sm.AA[i * LS + jz] = 0.f; sm.Dm[i * LS + jz] = 0.f;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int tt = wave + NWAVES * t;
+        if (tt < NT * NT) {
+          const f32x4& acc = t ? acc1 : acc0;
+          const int mi = tt / NT, nj = tt % NT, j = 16 * nj + lr;
+          const float rxj = sm.rx[j];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = 16 * mi + 4 * lq + r;
+            if (i < LR) {
+              float a = 0.f, d = 0.f;
+              if (i < P && j < P) pow_map(acc[r] * sm.rx[i] * rxj, pb.p, pb.clamp, a, d);
+              sm.AA[i * LS + j] = a;
+              sm.Dm[i * LS + j] = d;
+            }
           }
         }
       }
