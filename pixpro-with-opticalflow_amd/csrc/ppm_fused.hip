@@ -668,34 +668,52 @@ ppm_fused_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* _
                   [&](int ks) { return sm.rv[4 * ks + lq]; },
                   [&](int nn, int ks) { return sm.AA[(4 * ks + lq) * LS + 16 * nn + lr]; });
   STAMP(5);
+  // Column norms of Y and of k with two barriers.  Y stays raw in its registers (its 1 / ||.|| enters the loss dot product
+  // and dY as per-column factors); every wave keeps its own copy of 1 / ||k_j|| in its slice of part1, so that no third
+  // barrier is needed to publish it.
   float ry[NT];      // 1 / ||Y[:, i]|| of this lane's columns
   {
-    float v[NT];
 #pragma unroll
     for (int nn = 0; nn < NT; ++nn) {
-      float s = 0.f;
+      float q = 0.f;
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s = __builtin_fmaf(Y[m][nn][r], Y[m][nn][r], s);
-      v[nn] = s;
+        for (int r = 0; r < 4; ++r) q = __builtin_fmaf(Y[m][nn][r], Y[m][nn][r], q);
+      q += __shfl_xor(q, 16, 64);
+      q += __shfl_xor(q, 32, 64);
+      if (lane < 16) sm.part1[wave * 64 + 16 * nn + lane] = q;
     }
-    col_reduce_reg<NT>(v, sm.part1);       // the barrier inside also publishes k in B0
+    __syncthreads();                        // also publishes k in B0
+    if (pb.normalize_k) {
+      const int rows = C / NWAVES;
+      float a0 = 0.f, a1 = 0.f;
+      if (lane < P) {
+        const float* kp = sm.B0 + wave * rows * P + lane;
+        for (int c = 0; c < rows; c += 2) {
+          const float t0 = kp[c * P], t1 = kp[(c + 1) * P];
+          a0 = __builtin_fmaf(t0, t0, a0);
+          a1 = __builtin_fmaf(t1, t1, a1);
+        }
+      }
+      sm.part0[wave * 64 + lane] = a0 + a1;
+    }
 #pragma unroll
-    for (int nn = 0; nn < NT; ++nn) ry[nn] = 1.f / fmaxf(sqrtf(v[nn]), 1e-12f);
-  }
-  if (pb.normalize_k) {
-    col_rnorms(sm.B0, sm.rk, sm.part0, C, P);
-  } else {
-    if (tid < 64) sm.rk[tid] = 1.f;
+    for (int nn = 0; nn < NT; ++nn) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < NWAVES; ++w) t += sm.part1[w * 64 + 16 * nn + lr];
+      ry[nn] = 1.f / fmaxf(sqrtf(t), 1e-12f);
+    }
     __syncthreads();
-  }
+    float rkj = 1.f;
+    if (pb.normalize_k) {
+      float t = 0.f;
 #pragma unroll
-  for (int nn = 0; nn < NT; ++nn) {
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) Y[m][nn][r] = Y[m][nn][r] * ry[nn];
+      for (int w = 0; w < NWAVES; ++w) t += sm.part0[w * 64 + lane];
+      rkj = 1.f / fmaxf(sqrtf(t), 1e-12f);
+    }
+    sm.part1[wave * 64 + lane] = rkj;       // wave-private from here to the end of the G contraction
   }
   if (dd.pred) {
     float* gp = dd.pred + (size_t)n * tile;
@@ -706,7 +724,7 @@ ppm_fused_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* _
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int i = 16 * nn + lr;
-          if (i < P) gp[nhwc ? (size_t)i * C + crow(m, r) : (size_t)crow(m, r) * P + i] = Y[m][nn][r];
+          if (i < P) gp[nhwc ? (size_t)i * C + crow(m, r) : (size_t)crow(m, r) * P + i] = Y[m][nn][r] * ry[nn];
         }
   }
   STAMP(6);
@@ -727,14 +745,14 @@ ppm_fused_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* _
     }
     gemm_cp<MT, NT>(G, KS,
                     [&](int m, int ks) { return sm.B0[arow(m) * P + 4 * ks + lq]; },
-                    [&](int ks) { return sm.rk[4 * ks + lq]; },
+                    [&](int ks) { return sm.part1[wave * 64 + 4 * ks + lq]; },
                     [&](int nn, int ks) {
                       const unsigned w = ks < 8 ? lo[nn] : hi[nn];
                       return (float)((w >> ((4 * ks) & 31)) & 1u);
                     });
   }
   STAMP(7);
-  float tc[NT];      // <Y_hat[:, i], G[:, i]> of this lane's columns
+  float tc[NT];      // <Y_hat[:, i], G[:, i]> of this lane's columns (Y raw in registers: ry applied after the reduction)
   {
     float v[NT];
 #pragma unroll
@@ -746,9 +764,10 @@ ppm_fused_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* _
         for (int r = 0; r < 4; ++r) s = __builtin_fmaf(Y[m][nn][r], G[m][nn][r], s);
       v[nn] = s;
     }
-    col_reduce_reg<NT>(v, sm.part1);       // barrier: every wave is done reading k from B0
+    col_reduce_reg<NT>(v, sm.part1);       // a wave overwrites only its own slice (its 1 / ||k|| copy, no longer needed);
+                                           // barrier: every wave is done reading k from B0
 #pragma unroll
-    for (int nn = 0; nn < NT; ++nn) tc[nn] = v[nn];
+    for (int nn = 0; nn < NT; ++nn) tc[nn] = v[nn] * ry[nn];
   }
   const float cnt = sm.misc[1];
   const float den = cnt + 1e-6f;
@@ -774,11 +793,12 @@ ppm_fused_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* _
     for (int nn = 0; nn < NT; ++nn) {
       const int i = 16 * nn + lr;
       if (i < P) {
-        const float ti = gs * tc[nn], ryv = ry[nn];
+        // (gs G - Y_hat ti) ry with Y_hat = Y ry, ti = gs <Y_hat, G>:  G (gs ry) - Y (ry ry ti)
+        const float ryv = ry[nn], ga = gs * ryv, yb = ryv * ryv * (gs * tc[nn]);
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) sm.B0[crow(m, r) * P + i] = (gs * G[m][nn][r] - Y[m][nn][r] * ti) * ryv;
+          for (int r = 0; r < 4; ++r) sm.B0[crow(m, r) * P + i] = __builtin_fmaf(-Y[m][nn][r], yb, G[m][nn][r] * ga);
       }
     }
   }
@@ -836,10 +856,10 @@ ppm_fused_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* _
       for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          vh[m][nn][r] = (j < P) ? sm.B1[crow(m, r) * P + j] * rvj : 0.f;
+          vh[m][nn][r] = (j < P) ? sm.B1[crow(m, r) * P + j] : 0.f;        // raw v: rv folded into the factors below
           s = __builtin_fmaf(vh[m][nn][r], T[m][nn][r], s);
         }
-      v[nn] = s;
+      v[nn] = s * rvj;
     }
     col_reduce_reg<NT>(v, sm.part0);         // barrier: every wave is done reading dY from B0
     PUT_TILE(pfa, sm.B0);                    // x -> B0 (second read)
@@ -847,11 +867,11 @@ ppm_fused_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* _
     for (int nn = 0; nn < NT; ++nn) {
       const int j = 16 * nn + lr;
       if (j < P) {
-        const float sj = v[nn], rvj = sm.rv[j];
+        const float rvj = sm.rv[j], cj = rvj * rvj * v[nn];      // (T - v_hat s) rv = T rv - v (rv rv s)
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) sm.B1[crow(m, r) * P + j] = (T[m][nn][r] - vh[m][nn][r] * sj) * rvj;
+          for (int r = 0; r < 4; ++r) sm.B1[crow(m, r) * P + j] = __builtin_fmaf(-vh[m][nn][r], cj, T[m][nn][r] * rvj);
       }
     }
   }
@@ -882,21 +902,21 @@ ppm_fused_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* _
       for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          xh[m][nn][r] = (j < P) ? sm.B0[crow(m, r) * P + j] * rxj : 0.f;
+          xh[m][nn][r] = (j < P) ? sm.B0[crow(m, r) * P + j] : 0.f;        // raw x
           s = __builtin_fmaf(xh[m][nn][r], T[m][nn][r], s);
         }
-      v[nn] = s;
+      v[nn] = s * rxj;
     }
     col_reduce_reg<NT>(v, sm.part1);         // barrier: every wave is done reading x from B0
 #pragma unroll
     for (int nn = 0; nn < NT; ++nn) {
       const int j = 16 * nn + lr;
       if (j < P) {
-        const float sj = v[nn], rxj = sm.rx[j];
+        const float rxj = sm.rx[j], cj = rxj * rxj * v[nn];
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) sm.B0[crow(m, r) * P + j] = (T[m][nn][r] - xh[m][nn][r] * sj) * rxj;
+          for (int r = 0; r < 4; ++r) sm.B0[crow(m, r) * P + j] = __builtin_fmaf(-xh[m][nn][r], cj, T[m][nn][r] * rxj);
       }
     }
   }
