@@ -284,12 +284,16 @@ __device__ __forceinline__ void gemm_pp(f32x4& acc0, f32x4& acc1, const float* _
   if (!has0) return;
   const int i0 = min(16 * (t0 / NT) + lr, P - 1), j0 = min(16 * (t0 % NT) + lr, P - 1);
   const int i1 = has1 ? min(16 * (t1 / NT) + lr, P - 1) : i0, j1 = has1 ? min(16 * (t1 % NT) + lr, P - 1) : j0;
-  const float* la = L + lq * P + i0;
-  const float* rb = R + lq * P + j0;
-  const float* lc = L + lq * P + i1;
-  const float* rd = R + lq * P + j1;
-  const int step = 4 * P;
+  // K order: the four k of one MFMA step are 16 rows apart (row = 64 (ks / 16) + ks % 16 + 16 lq) instead of adjacent:
+  // with P = 49 the four lane groups then read bank windows 16 apart (49 * 16 = 16 mod 64) - no conflicts - where
+  // adjacent rows overlap by one bank each (2-way conflicts on every operand read of the two P x P contractions).
+  const float* la = L + 16 * lq * P + i0;
+  const float* rb = R + 16 * lq * P + j0;
+  const float* lc = L + 16 * lq * P + i1;
+  const float* rd = R + 16 * lq * P + j1;
+  const int step = P;
   const int nblk = C / 4 / KU;
+  static_assert(KU == 8, "two blocks of KU steps walk one group of 64 rows");
   float a[KU], b[KU], c[KU], d[KU];
 #pragma unroll
   for (int u = 0; u < KU; ++u) {
@@ -298,7 +302,7 @@ __device__ __forceinline__ void gemm_pp(f32x4& acc0, f32x4& acc1, const float* _
   }
   for (int blk = 0; blk < nblk; ++blk) {
     float an[KU], bn[KU], cn[KU], dn[KU];
-    const int adv = blk + 1 < nblk ? KU * step : 0;     // the last block re-reads itself (never used)
+    const int adv = blk + 1 < nblk ? ((blk & 1) ? 56 * step : 8 * step) : 0;     // the last block re-reads itself (never used)
     la += adv; rb += adv; lc += adv; rd += adv;
 #pragma unroll
     for (int u = 0; u < KU; ++u) {
@@ -325,9 +329,9 @@ __device__ __forceinline__ void gemm_pp(f32x4& acc0, f32x4& acc1, const float* _
 __device__ __forceinline__ f32x4 gemm_pp_tile(const float* __restrict__ L, const float* __restrict__ R, int C, int P,
                                               int ti, int tj) {
   const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
-  const float* la = L + lq * P + min(16 * ti + lr, P - 1);
-  const float* rb = R + lq * P + min(16 * tj + lr, P - 1);
-  const int step = 4 * P;
+  const float* la = L + 16 * lq * P + min(16 * ti + lr, P - 1);       // K order as in gemm_pp
+  const float* rb = R + 16 * lq * P + min(16 * tj + lr, P - 1);
+  const int step = P;
   const int nblk = C / 4 / KU;
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
   float a[KU], b[KU];
@@ -335,7 +339,7 @@ __device__ __forceinline__ f32x4 gemm_pp_tile(const float* __restrict__ L, const
   for (int u = 0; u < KU; ++u) { a[u] = la[u * step]; b[u] = rb[u * step]; }
   for (int blk = 0; blk < nblk; ++blk) {
     float an[KU], bn[KU];
-    const int adv = blk + 1 < nblk ? KU * step : 0;     // the last block re-reads itself (never used)
+    const int adv = blk + 1 < nblk ? ((blk & 1) ? 56 * step : 8 * step) : 0;     // the last block re-reads itself (never used)
     la += adv; rb += adv;
 #pragma unroll
     for (int u = 0; u < KU; ++u) { an[u] = la[u * step]; bn[u] = rb[u * step]; }
