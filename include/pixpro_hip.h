@@ -159,6 +159,18 @@ int pixpro_flow_prepare(const float* lo_fwd, const float* lo_bwd, float* flow_fw
                         float* flow_bwd, uint8_t* mask_fwd, uint8_t* mask_bwd,
                         int32_t* invalid_count, int32_t N, int32_t F1, int32_t h, int32_t w,
                         int32_t flow_up, float alpha1, double alpha2, void* stream);
+/* The same with a caller-owned scratch buffer (16-B aligned, pixpro_flow_prepare_workspace_bytes; 0 for F1 == 1 and for
+ * the shapes the generic kernels take).  With it the masks of F1 > 1 (the production recipe is nframe = 6) take the
+ * certified route of F1 == 1: the chain launch leaves the bounding box of every 8 x 8-pixel block of both composed
+ * flows in the workspace, one launch settles every pixel those boxes can settle and a third one the tiles they cannot
+ * (bit-identical to the route without workspace; replaces the same reference lines, util.py:174-248). */
+size_t pixpro_flow_prepare_workspace_bytes(int32_t N, int32_t F1, int32_t h, int32_t w, int32_t flow_up);
+int pixpro_flow_prepare_ws(const float* lo_fwd, const float* lo_bwd, float* flow_fwd,
+                           float* flow_bwd, uint8_t* mask_fwd, uint8_t* mask_bwd,
+                           int32_t* invalid_count, int32_t N, int32_t F1, int32_t h, int32_t w,
+                           int32_t flow_up, float alpha1, double alpha2, void* workspace,
+                           size_t workspace_bytes, void* stream);
+
 /* calc_mask_ratio (util.py:360-366): ratio[n] = mean(!mask[n]). */
 int pixpro_mask_ratio(const uint8_t* mask, float* ratio, int32_t N, int64_t pixels,
                       void* stream);

@@ -56,6 +56,9 @@ SIGNATURES = {
     "pixpro_fbc_mask": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _f64, _i32, _vp]),
     "pixpro_flow_prepare": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32,
                                            _f32, _f64, _vp]),
+    "pixpro_flow_prepare_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32, _i32]),
+    "pixpro_flow_prepare_ws": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32,
+                                              _f32, _f64, _vp, _sz, _vp]),
     "pixpro_mask_ratio": (ctypes.c_int, [_vp, _vp, _i32, _i64, _vp]),
     "pixpro_ema_update": (ctypes.c_int, [_vp, _vp, _vp, _i32, _f64, _vp]),
     "pixpro_lars_sgd_step": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _f32, _f32, _f32, _f32, _i32,

@@ -270,6 +270,20 @@ def mem_reduce_calc_optical_flow(orig_imgs, flow_model, args):
     return flow_fwd.unsqueeze(0), flow_bwd.unsqueeze(0)
 
 
+_FLOW_WS = {}
+
+
+def _flow_workspace(dev, nbytes):
+    """One cached scratch buffer per device (stream-ordered reuse: every call enqueues on the current stream)."""
+    if nbytes <= 0:
+        return None
+    buf = _FLOW_WS.get(dev)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        _FLOW_WS[dev] = buf
+    return buf
+
+
 @torch.no_grad()
 def apply_optical_flow(data, flow_model, args):
     """The reference's apply_optical_flow (util.py:174-248), fused: permute + upflow8 + concat_flow (both directions) +
@@ -308,9 +322,13 @@ def apply_optical_flow(data, flow_model, args):
         mask_fwd = torch.empty((N, Hf, Wf), dtype=torch.bool, device=dev)
         mask_bwd = torch.empty_like(mask_fwd)
         counts = torch.empty(2 * N, dtype=torch.int32, device=dev)
-    nv.call("pixpro_flow_prepare", nv.ptr(lo_f), nv.ptr(lo_b), nv.ptr(flow_fwd), nv.ptr(flow_bwd),
+    # scratch of the certified mask route for nframe > 2 (block bounding boxes of the composed flows); 0 bytes otherwise
+    ws_bytes = nv.load().pixpro_flow_prepare_workspace_bytes(N, F1, h, w, int(up)) if is_mask else 0
+    ws = _flow_workspace(dev, ws_bytes)
+    nv.call("pixpro_flow_prepare_ws", nv.ptr(lo_f), nv.ptr(lo_b), nv.ptr(flow_fwd), nv.ptr(flow_bwd),
             nv.ptr(mask_fwd), nv.ptr(mask_bwd), nv.ptr(counts), N, F1, h, w, int(up),
-            float(args.alpha1) if is_mask else 0.0, float(args.alpha2) if is_mask else 0.0, nv.stream())
+            float(args.alpha1) if is_mask else 0.0, float(args.alpha2) if is_mask else 0.0,
+            nv.ptr(ws), ws_bytes if ws is not None else 0, nv.stream())
     if is_mask:
         mask_fwd = MaskWithCounts.wrap(mask_fwd, counts[:N])
         mask_bwd = MaskWithCounts.wrap(mask_bwd, counts[N:])

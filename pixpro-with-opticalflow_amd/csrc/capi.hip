@@ -46,7 +46,8 @@ int run_fbc(const float* f, const float* b, uint8_t* mask, float* cycle, int N, 
             double alpha2, int is_norm, hipStream_t st);
 int run_flow_prepare(const float* lo_fwd, const float* lo_bwd, float* flow_fwd, float* flow_bwd, uint8_t* mask_fwd,
                      uint8_t* mask_bwd, int32_t* invalid, int N, int F1, int h, int w, int flow_up, float alpha1,
-                     double alpha2, hipStream_t st);
+                     double alpha2, void* workspace, size_t workspace_bytes, hipStream_t st);
+size_t flow_prepare_workspace_bytes(int N, int F1, int h, int w, int flow_up);
 int run_mask_ratio(const uint8_t* mask, float* ratio, int N, int64_t pixels, hipStream_t st);
 int run_add_optical_flow(const pixpro_problem& pb, const float* flow, const float* xg, const float* yg,
                          const uint8_t* mask, float* ox, float* oy, uint8_t* mg, hipStream_t st);
@@ -227,7 +228,25 @@ int pixpro_flow_prepare(const float* lo_fwd, const float* lo_bwd, float* flow_fw
   if ((mask_fwd == nullptr) != (mask_bwd == nullptr)) return bad("mask_fwd and mask_bwd go together");
   if (N < 1 || F1 < 1 || h < 2 || w < 2) return bad("N, F1 >= 1 and h, w >= 2 required");
   return run_flow_prepare(lo_fwd, lo_bwd, flow_fwd, flow_bwd, mask_fwd, mask_bwd, invalid_count, N, F1, h, w,
-                          flow_up, alpha1, alpha2, (hipStream_t)stream);
+                          flow_up, alpha1, alpha2, nullptr, 0, (hipStream_t)stream);
+}
+
+size_t pixpro_flow_prepare_workspace_bytes(int32_t N, int32_t F1, int32_t h, int32_t w, int32_t flow_up) {
+  if (N < 1 || F1 < 1 || h < 2 || w < 2) return 0;
+  return flow_prepare_workspace_bytes(N, F1, h, w, flow_up);
+}
+
+int pixpro_flow_prepare_ws(const float* lo_fwd, const float* lo_bwd, float* flow_fwd, float* flow_bwd,
+                           uint8_t* mask_fwd, uint8_t* mask_bwd, int32_t* invalid_count, int32_t N, int32_t F1,
+                           int32_t h, int32_t w, int32_t flow_up, float alpha1, double alpha2, void* workspace,
+                           size_t workspace_bytes, void* stream) {
+  if (!lo_fwd || !lo_bwd || !flow_fwd || !flow_bwd) return bad("null pointer");
+  if ((mask_fwd == nullptr) != (mask_bwd == nullptr)) return bad("mask_fwd and mask_bwd go together");
+  if (N < 1 || F1 < 1 || h < 2 || w < 2) return bad("N, F1 >= 1 and h, w >= 2 required");
+  if (workspace && workspace_bytes < flow_prepare_workspace_bytes(N, F1, h, w, flow_up))
+    return bad("workspace smaller than pixpro_flow_prepare_workspace_bytes");
+  return run_flow_prepare(lo_fwd, lo_bwd, flow_fwd, flow_bwd, mask_fwd, mask_bwd, invalid_count, N, F1, h, w,
+                          flow_up, alpha1, alpha2, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 int pixpro_mask_ratio(const uint8_t* mask, float* ratio, int32_t N, int64_t pixels, void* stream) {

@@ -730,9 +730,11 @@ __device__ __forceinline__ float2 chain_tap(const ChainWin& cwn, const AxF& ay, 
                      8.f * up8_col(up8_row(a.y, b.y, ax.l0, ax.l1), up8_row(c.y, d.y, ax.l0, ax.l1), ay.l0, ay.l1));
 }
 
-__global__ void __launch_bounds__(NT_C)
+// (6 waves per SIMD = 80 VGPRs: the block boxes must not cost the chain an occupancy step - 83 VGPRs without the hint,
+// measured 2.2 -> 2.5 ms)
+__global__ void __launch_bounds__(NT_C) __attribute__((amdgpu_waves_per_eu(6, 8)))
 k_chain_up8(const float* __restrict__ lo_fwd, const float* __restrict__ lo_bwd, float* __restrict__ flow_fwd,
-            float* __restrict__ flow_bwd, int N, int F1, Up8Geom g) {
+            float* __restrict__ flow_bwd, float4* __restrict__ bbox, int N, int F1, Up8Geom g) {
   __shared__ float2 lwc[CH_MAXF][CWH * CWW];   // low-res cells of every flow under the tile + margin, replicate-padded
   const int n = blockIdx.z >> 1, dir = blockIdx.z & 1, t = threadIdx.x;
   const size_t hw = (size_t)g.h * g.w, HW = (size_t)g.Hf * g.Wf;
@@ -748,8 +750,14 @@ k_chain_up8(const float* __restrict__ lo_fwd, const float* __restrict__ lo_bwd, 
   }
   __syncthreads();
   const int x = tx0 + lane;
-  if (x >= g.Wf) return;
+  if (x >= g.Wf) return;                 // Wf = 8 w: whole groups of eight lanes leave together
   const float x0f = (float)x;
+  // by-product for the certified mask kernel: {min x, max x, min y, max y} of the composed flow over every 8 x 8 block
+  // (tile origins and the 16 rows of a wave are multiples of 8; Hf = 8 h); +-inf when a block holds a non-finite value
+  const float INF = __builtin_huge_valf();
+  float4 bb = make_float4(INF, -INF, INF, -INF);
+  bool odd = false;
+  float4* bbn = bbox ? bbox + (size_t)blockIdx.z * (g.Hf / 8) * (g.Wf / 8) : nullptr;
 #pragma unroll 2
   for (int i = 0; i < ROWS_C; ++i) {
     const int y = ty0 + wave * ROWS_C + i;
@@ -801,8 +809,25 @@ k_chain_up8(const float* __restrict__ lo_fwd, const float* __restrict__ lo_bwd, 
       cx = cx + fx; cy = cy + fy;
     }
     const size_t q = (size_t)y * g.Wf + x;
-    out[q] = cx - x0f;
-    out[HW + q] = cy - (float)y;
+    const float ox = cx - x0f, oy = cy - (float)y;
+    out[q] = ox;
+    out[HW + q] = oy;
+    if (bbn) {
+      bb.x = fminf(bb.x, ox); bb.y = fmaxf(bb.y, ox); bb.z = fminf(bb.z, oy); bb.w = fmaxf(bb.w, oy);
+      odd = odd || !(fabsf(ox) < INF && fabsf(oy) < INF);
+      if ((i & 7) == 7) {
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {
+          bb.x = fminf(bb.x, __shfl_xor(bb.x, o, 64)); bb.y = fmaxf(bb.y, __shfl_xor(bb.y, o, 64));
+          bb.z = fminf(bb.z, __shfl_xor(bb.z, o, 64)); bb.w = fmaxf(bb.w, __shfl_xor(bb.w, o, 64));
+        }
+        const unsigned long long oddm = __ballot(odd);
+        if ((oddm >> (lane & ~7)) & 0xFFull) bb = make_float4(-INF, INF, -INF, INF);
+        if ((lane & 7) == 0) bbn[(size_t)(y >> 3) * (g.Wf / 8) + (x >> 3)] = bb;
+        bb = make_float4(INF, -INF, INF, -INF);
+        odd = false;
+      }
+    }
   }
 }
 
@@ -820,7 +845,7 @@ __device__ __attribute__((noinline)) bool fbc_dense_generic(const float* f, cons
 
 __global__ void __launch_bounds__(NT)
 k_fbc_pair(const float* __restrict__ flow_fwd, const float* __restrict__ flow_bwd, uint8_t* __restrict__ mask_fwd,
-           uint8_t* __restrict__ mask_bwd, int32_t* __restrict__ invalid, int N, Up8Geom g) {
+           uint8_t* __restrict__ mask_bwd, int32_t* __restrict__ invalid, int N, Up8Geom g, int marked_only) {
   __shared__ float2 no[RH * RW];           // normalised opposite flow over the region
   __shared__ float red[NWAVE][3];
   const int n = blockIdx.z >> 1, dir = blockIdx.z & 1, t = threadIdx.x;
@@ -829,6 +854,8 @@ k_fbc_pair(const float* __restrict__ flow_fwd, const float* __restrict__ flow_bw
   const float* o = (dir ? flow_fwd : flow_bwd) + (size_t)n * 2 * HW;
   uint8_t* mask = (dir ? mask_bwd : mask_fwd) + (size_t)n * HW;
   const int tx0 = blockIdx.x * TX, ty0 = blockIdx.y * TY;
+  // second launch behind k_fbc_cert_dense: only the tiles it marked (every thread reads the same byte: block-uniform)
+  if (marked_only && mask[(size_t)ty0 * g.Wf + tx0] != TILE_MARK) return;
   const int wave = t >> 6, lane = t & 63;
   const int x = tx0 + lane;
   float2 fn[CH_PX];
@@ -876,6 +903,197 @@ k_fbc_pair(const float* __restrict__ flow_fwd, const float* __restrict__ flow_bw
     bad += __popcll(__ballot(!ok));
   }
   if (invalid && lane == 0 && bad) atomicAdd(&invalid[dir * N + n], bad);
+}
+
+// ---- certified masks of DENSE composed flows (nframe > 2), both directions per block ------------------------------------
+// The certificate of k_prepare_cert, with the 8 x 8-pixel bounding boxes k_chain_up8 leaves behind in place of the
+// low-res cells: the taps of a pixel of block j displaced by a flow in [lo, hi] (the range of the tile's own flow) lie
+// in blocks j + floor((floor(lo) - 1) / 8) .. j + floor((7 + ceil(hi) + 1) / 8); the union of their boxes bounds b'.
+// A certified pixel costs its own two flow values (coalesced), the exact normalisation and ~12 instructions per
+// direction; pixels the boxes cannot settle are evaluated exactly; tiles where they cannot work are marked in BOTH masks
+// for k_fbc_pair (marked_only).  Bit-identical to k_fbc_pair either way.
+constexpr int TBX = TX / 8, TBY = TYC / 8;               // 8 x 10 blocks per tile
+constexpr int MB = 4;                                    // blocks of margin: own-flow RANGE inside a tile up to ~32 px
+constexpr int WBW = TBX + 2 * MB, WBH = TBY + 2 * MB;    // block window: 16 x 18
+
+__device__ __forceinline__ void block_offsets(float dlo, float dhi, int& o_lo, int& o_hi) {
+  const float a = floorf(dlo) - 1.f, b = ceilf(dhi) + 1.f;
+  o_lo = (int)floorf(a * 0.125f);
+  o_hi = (int)floorf((7.f + b) * 0.125f);
+}
+// [lo, hi] of raw flow values (pixels) -> box of the normalised flow 2 f / (size - 1), inflated for rounding
+__device__ __forceinline__ void norm_box_dense(float lo, float hi, const DivC& d, float& L, float& U) {
+  const float s = BOX_SLOP * fmaxf(fabsf(lo), fabsf(hi));
+  L = div_c(2.f * (lo - s), d);
+  U = div_c(2.f * (hi + s), d);
+  const float s2 = BOX_SLOP * fmaxf(fabsf(L), fabsf(U));
+  L -= s2; U += s2;
+}
+
+__global__ void __launch_bounds__(NT_C)
+k_fbc_cert_dense(const float* __restrict__ flow_fwd, const float* __restrict__ flow_bwd, const float4* __restrict__ bbox,
+                 uint8_t* __restrict__ mask_fwd, uint8_t* __restrict__ mask_bwd, int32_t* __restrict__ invalid, int N,
+                 Up8Geom g, int force) {
+  __shared__ float4 ow[2][WBH * WBW];      // opposite-direction boxes around where the tile lands, per direction
+  __shared__ float4 tmp[2][WBH * TBX];     // row pass
+  __shared__ float4 tab[2][TBY * TBX];     // per own block: normalised, inflated box {Lx, Ux, Ly, Uy} of the opposite flow
+  __shared__ float part0[2][4];            // {min x, max x, min y, max y} of the tile's own flow, per direction
+  __shared__ int wide_boxes;
+  const int n = blockIdx.z, t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int tx0 = blockIdx.x * TX, ty0 = blockIdx.y * TYC;
+  const int Wb = g.Wf / 8, Hb = g.Hf / 8, bx0 = tx0 / 8, by0 = ty0 / 8;
+  const int ucols = min(TBX, Wb - bx0), urows = min(TBY, Hb - by0);
+  const size_t HW = (size_t)g.Hf * g.Wf, HWb = (size_t)Hb * Wb;
+  const float INF = __builtin_huge_valf();
+  const float4* bbd[2] = {bbox + (size_t)(2 * n) * HWb, bbox + (size_t)(2 * n + 1) * HWb};   // boxes of fwd, bwd
+  if (t == 0) wide_boxes = 0;
+  // ---- range of the tile's own flows: waves 0, 1 take direction 0, waves 2, 3 direction 1 (80 blocks each)
+  if (wave < 4) {
+    const int d = wave >> 1, e = t - d * 128;
+    float4 m = make_float4(INF, -INF, INF, -INF);
+    if (e < TBY * TBX) {
+      const int r = e / TBX, c = e - r * TBX;
+      if (r < urows && c < ucols) m = bbd[d][(size_t)(by0 + r) * Wb + bx0 + c];
+    }
+    m.x = wave_min(m.x); m.y = wave_max(m.y); m.z = wave_min(m.z); m.w = wave_max(m.w);
+    if (lane == 0) { tmp[0][wave] = m; }
+  }
+  __syncthreads();
+  if (t < 2) {
+    const float4 a = tmp[0][2 * t], b = tmp[0][2 * t + 1];
+    part0[t][0] = fminf(a.x, b.x); part0[t][1] = fmaxf(a.y, b.y); part0[t][2] = fminf(a.z, b.z); part0[t][3] = fmaxf(a.w, b.w);
+  }
+  __syncthreads();
+  bool certify = force != 2;                              // block-uniform throughout
+  int ox[2] = {0, 0}, oy[2] = {0, 0}, ex[2] = {0, 0}, ey[2] = {0, 0}, shx[2] = {0, 0}, shy[2] = {0, 0};
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    float lo[2], hi[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      lo[k] = part0[d][2 * k]; hi[k] = part0[d][2 * k + 1];
+      // false for NaN / inf too; the magnitude bound keeps the casts below in range (such a tile is far outside anyway)
+      certify = certify && (hi[k] - lo[k] <= 8.f * MB * 2.f) && fabsf(lo[k]) <= 1e6f && fabsf(hi[k]) <= 1e6f;
+    }
+    if (certify) {
+      block_offsets(lo[0], hi[0], ox[d], ex[d]);
+      block_offsets(lo[1], hi[1], oy[d], ey[d]);
+      const int span_x = MB + (TBX - ucols), span_y = MB + (TBY - urows);
+      certify = ex[d] - ox[d] <= MB + span_x && ey[d] - oy[d] <= MB + span_y;
+      shx[d] = min(max((ox[d] + ex[d]) / 2, ex[d] - span_x), ox[d] + MB);
+      shy[d] = min(max((oy[d] + ey[d]) / 2, ey[d] - span_y), oy[d] + MB);
+    }
+  }
+  certify = uniform(certify);
+  if (certify) {                                          // the windows: direction d samples the boxes of direction 1 - d
+    for (int e = t; e < 2 * WBH * WBW; e += NT_C) {
+      const int d = e >= WBH * WBW, q = e - d * WBH * WBW, r = q / WBW, c = q - r * WBW;
+      const int br = min(max(by0 - MB + shy[d] + r, 0), Hb - 1), bc = min(max(bx0 - MB + shx[d] + c, 0), Wb - 1);
+      ow[d][q] = bbd[1 - d][(size_t)br * Wb + bc];
+    }
+  }
+  __syncthreads();
+  if (certify) {                                          // row pass
+    for (int e = t; e < 2 * WBH * TBX; e += NT_C) {
+      const int d = e >= WBH * TBX, q = e - d * WBH * TBX, r = q / TBX, j = q - r * TBX;
+      if (r >= MB + oy[d] - shy[d] && r <= MB + urows - 1 + ey[d] - shy[d] && j < ucols) {
+        float4 m = make_float4(INF, -INF, INF, -INF);
+        for (int k = ox[d] - shx[d]; k <= ex[d] - shx[d]; ++k) {
+          const float4 v = ow[d][r * WBW + MB + j + k];
+          m.x = fminf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fminf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+        }
+        tmp[d][q] = m;
+      }
+    }
+  }
+  __syncthreads();
+  if (certify) {                                          // column pass -> normalised boxes
+    for (int e = t; e < 2 * TBY * TBX; e += NT_C) {
+      const int d = e >= TBY * TBX, q = e - d * TBY * TBX, i = q / TBX, j = q - i * TBX;
+      if (i < urows && j < ucols) {
+        float4 m = make_float4(INF, -INF, INF, -INF);
+        for (int k = oy[d] - shy[d]; k <= ey[d] - shy[d]; ++k) {
+          const float4 v = tmp[d][(MB + i + k) * TBX + j];
+          m.x = fminf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fminf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+        }
+        float4 b;
+        norm_box_dense(m.x, m.y, g.wd, b.x, b.y);
+        norm_box_dense(m.z, m.w, g.ht, b.z, b.w);
+        tab[d][q] = b;
+        const float wxb = b.y - b.x, wyb = b.w - b.z;
+        if (!(wxb * wxb + wyb * wyb <= g.a2)) atomicAdd(&wide_boxes, 1);     // cannot certify anything (NaN / inf too)
+      }
+    }
+  }
+  __syncthreads();
+  if (force != 1) certify = certify && 4 * wide_boxes <= 2 * urows * ucols;
+  certify = uniform(certify);
+  if (!certify) {                                         // both staged tiles under this one, in both masks
+    if (t < 4 && ty0 + (t & 1) * TY < g.Hf)
+      ((t & 2) ? mask_bwd : mask_fwd)[(size_t)n * HW + (size_t)(ty0 + (t & 1) * TY) * g.Wf + tx0] = TILE_MARK;
+    return;
+  }
+  const float a2c = g.a2 * (1.f - 2.f * BOX_SLOP);
+  const int x = tx0 + lane;
+  if (x >= g.Wf) return;                                  // whole waves' lane groups; no barrier below
+  const float c0x = div_c(2.f * (float)x, g.wd) - 1.f;
+  const float* ff = flow_fwd + (size_t)n * 2 * HW + x;
+  const float* fb = flow_bwd + (size_t)n * 2 * HW + x;
+  const int bj = lane >> 3;
+  int badf = 0, badb = 0;
+  unsigned undecided = 0;
+  const int yw = ty0 + wave * ROWS_C;
+  float4 bxf = make_float4(0.f, 0.f, 0.f, 0.f), bxb = bxf;
+#pragma unroll 4
+  for (int rr = 0; rr < ROWS_C; ++rr) {
+    const int y = yw + rr;
+    if (y >= g.Hf) break;                                 // wave-uniform
+    if ((rr & 7) == 0) {
+      const int ci = ((y - ty0) >> 3) * TBX + bj;
+      bxf = tab[0][ci]; bxb = tab[1][ci];
+    }
+    const size_t q = (size_t)y * g.Wf;
+    const float c0y = div_c(2.f * (float)y, g.ht) - 1.f;
+    const float fn[2][2] = {{div_c(2.f * ff[q], g.wd), div_c(2.f * ff[HW + q], g.ht)},
+                            {div_c(2.f * fb[q], g.wd), div_c(2.f * fb[HW + q], g.ht)}};
+    bool ok[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      const float4 bx = d ? bxb : bxf;
+      const float c1x = c0x + fn[d][0], c1y = c0y + fn[d][1];
+      const bool inside = (fabsf(c1x) < 1.f) && (fabsf(c1y) < 1.f);
+      const float mx = fmaxf(fabsf(fn[d][0] + bx.x), fabsf(fn[d][0] + bx.y));
+      const float my = fmaxf(fabsf(fn[d][1] + bx.z), fabsf(fn[d][1] + bx.w));
+      const bool sure = __builtin_fmaf(mx, mx, my * my) <= a2c;
+      ok[d] = inside && sure;
+      if (inside && !sure) undecided |= 1u << (2 * rr + d);
+    }
+    mask_fwd[(size_t)n * HW + q + x] = ok[0] ? 1 : 0;
+    mask_bwd[(size_t)n * HW + q + x] = ok[1] ? 1 : 0;
+    badf += __popcll(__ballot(!ok[0]));
+    badb += __popcll(__ballot(!ok[1]));
+  }
+  while (__any(undecided != 0)) {
+    bool fixed_f = false, fixed_b = false;
+    if (undecided) {
+      const int bit = __builtin_ctz(undecided);
+      undecided &= undecided - 1;
+      const int d = bit & 1, y = yw + (bit >> 1);
+      const float* fo = flow_fwd + (size_t)n * 2 * HW;
+      const float* bo = flow_bwd + (size_t)n * 2 * HW;
+      if (fbc_dense_generic(d ? bo : fo, d ? fo : bo, g.Hf, g.Wf, y, x, g.alpha1, g.a2)) {
+        (d ? mask_bwd : mask_fwd)[(size_t)n * HW + (size_t)y * g.Wf + x] = 1;
+        fixed_f = d == 0; fixed_b = d == 1;
+      }
+    }
+    badf -= __popcll(__ballot(fixed_f));
+    badb -= __popcll(__ballot(fixed_b));
+  }
+  if (invalid && (lane & 63) == __builtin_ctzll(__ballot(true))) {
+    if (badf) atomicAdd(&invalid[n], badf);
+    if (badb) atomicAdd(&invalid[N + n], badb);
+  }
 }
 
 // ---- K8: calc_mask_ratio -----------------------------------------------------------------
@@ -955,9 +1173,15 @@ static Up8Geom make_geom(int h, int w, int Hf, int Wf, float alpha1, float a2) {
   return g;
 }
 
+// Scratch of the certified mask path for F1 > 1: one float4 box per 8 x 8 block of both composed flows.
+size_t flow_prepare_workspace_bytes(int N, int F1, int h, int w, int flow_up) {
+  if (F1 <= 1 || !flow_up || !up8_separable(h, w) || F1 > CH_MAXF) return 0;
+  return (size_t)2 * N * h * w * sizeof(float4);
+}
+
 int run_flow_prepare(const float* lo_fwd, const float* lo_bwd, float* flow_fwd, float* flow_bwd, uint8_t* mask_fwd,
                      uint8_t* mask_bwd, int32_t* invalid, int N, int F1, int h, int w, int flow_up, float alpha1,
-                     double alpha2, hipStream_t st) {
+                     double alpha2, void* workspace, size_t workspace_bytes, hipStream_t st) {
   const int Hf = flow_up ? 8 * h : h, Wf = flow_up ? 8 * w : w;
   const size_t n = (size_t)N * Hf * Wf;
   const float a2 = fbc_a2(alpha2, Hf, Wf);
@@ -1002,12 +1226,26 @@ int run_flow_prepare(const float* lo_fwd, const float* lo_bwd, float* flow_fwd, 
   // F-1 > 1: chains (both directions in one launch), then both masks in one launch
   if (tiled && F1 <= CH_MAXF) {
     const Up8Geom g = make_geom(h, w, Hf, Wf, alpha1, a2);
+    // With a workspace (pixpro_flow_prepare_ws) the masks take the certified route: the chain leaves the bounding box of
+    // every 8 x 8 block behind, k_fbc_cert_dense settles what those boxes can settle and marks the other tiles for
+    // k_fbc_pair.  PIXPRO_FLOW_PATH as for F1 == 1.  Without one: k_fbc_pair on every tile (round 1's route).
+    const char* path = getenv("PIXPRO_FLOW_PATH");
+    int force = !path ? 0 : !strcmp(path, "certified") ? 1 : !strcmp(path, "staged") ? 2 : 0;
+    if (!(alpha1 >= 0.f)) force = 2;        // the certificate needs eps >= a2, i.e. alpha1 >= 0
+    const bool cert = mask_fwd && workspace && ((uintptr_t)workspace & 15) == 0 &&
+                      workspace_bytes >= flow_prepare_workspace_bytes(N, F1, h, w, flow_up);
+    float4* bbox = cert ? (float4*)workspace : nullptr;
     hipLaunchKernelGGL(k_chain_up8, dim3(grid.x, (Hf + TYC - 1) / TYC, 2 * N), dim3(NT_C), 0, st, lo_fwd, lo_bwd, flow_fwd,
-                       flow_bwd, N, F1, g);
+                       flow_bwd, bbox, N, F1, g);
     CHECKED("k_chain_up8");
     if (mask_fwd) {
+      if (cert) {
+        hipLaunchKernelGGL(k_fbc_cert_dense, dim3(grid.x, (Hf + TYC - 1) / TYC, N), dim3(NT_C), 0, st, flow_fwd, flow_bwd,
+                           bbox, mask_fwd, mask_bwd, invalid, N, g, force);
+        CHECKED("k_fbc_cert_dense");
+      }
       hipLaunchKernelGGL(k_fbc_pair, dim3(grid.x, grid.y, 2 * N), dim3(NT), 0, st, flow_fwd, flow_bwd, mask_fwd,
-                         mask_bwd, invalid, N, g);
+                         mask_bwd, invalid, N, g, cert ? 1 : 0);
       CHECKED("k_fbc_pair");
     }
     return PIXPRO_OK;
@@ -1025,7 +1263,7 @@ int run_flow_prepare(const float* lo_fwd, const float* lo_bwd, float* flow_fwd, 
   if (mask_fwd) {
     if (2 * N <= 65535 && grid.y <= 65535) {       // dense inputs: the tiled mask kernel does not up-sample anything
       hipLaunchKernelGGL(k_fbc_pair, dim3(grid.x, grid.y, 2 * N), dim3(NT), 0, st, flow_fwd, flow_bwd, mask_fwd,
-                         mask_bwd, invalid, N, make_geom(h, w, Hf, Wf, alpha1, a2));
+                         mask_bwd, invalid, N, make_geom(h, w, Hf, Wf, alpha1, a2), 0);
       CHECKED("k_fbc_pair");
     } else {
       hipLaunchKernelGGL(k_fbc, dim3(blocks_for(n)), dim3(TPB), 0, st, flow_fwd, flow_bwd, mask_fwd, (float*)nullptr,

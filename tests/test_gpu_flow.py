@@ -148,19 +148,21 @@ def test_apply_optical_flow_bdd_size_batch_vs_oracle(dev, nfr, N):
     assert torch.allclose(r, (~mfo).float().mean((-1, -2)), atol=1e-6, rtol=0)
 
 
+@pytest.mark.parametrize("nfr", [2, 4])
 @pytest.mark.parametrize("case", ["nan", "inf", "huge", "alpha2_tiny", "alpha2_zero", "alpha1_zero", "alpha1_negative",
                                   "coherent_40px", "coherent_18px", "motion_boundary", "zero"])
-def test_flow_prepare_adversarial_inputs_vs_oracle(dev, case):
-    """The certified nframe=2 kernel decides most mask bits from a bound; whatever the inputs do to that bound (NaN / Inf
-    cells, flows far beyond the window, tolerances that certify nothing, a motion boundary inside a tile) the bits must
-    stay the oracle's.  Several tiles per map (45x80 -> 360x640)."""
+def test_flow_prepare_adversarial_inputs_vs_oracle(dev, case, nfr):
+    """The certified kernels (nframe = 2: bound from the low-res cells; nframe > 2: bound from the block boxes of the
+    composed flows) decide most mask bits from a bound; whatever the inputs do to that bound (NaN / Inf cells, flows far
+    beyond the window, tolerances that certify nothing, a motion boundary inside a tile) the bits must stay the
+    oracle's.  Several tiles per map (45x80 -> 360x640)."""
     from contrast import util
     from oracle import pixpro_oracle as O
     from recipes import smooth_flow
     gen = torch.Generator().manual_seed(77)
-    N, hw = 2, (45, 80)
-    fw = smooth_flow((N, 1, 2, *hw), 0.5, gen)
-    bw = -fw + smooth_flow((N, 1, 2, *hw), 0.05, gen)
+    N, hw, F1 = 2, (45, 80), nfr - 1
+    fw = smooth_flow((N, F1, 2, *hw), 0.5 / F1, gen)
+    bw = -fw.flip(1) + smooth_flow((N, F1, 2, *hw), 0.05 / F1, gen)
     a1, a2 = 0.01, 0.5
     if case == "nan":
         fw[0, 0, 0, 10, 20] = float("nan"); bw[1, 0, 1, 30, 50] = float("nan")
@@ -185,7 +187,7 @@ def test_flow_prepare_adversarial_inputs_vs_oracle(dev, case):
     elif case == "zero":
         fw.zero_(); bw.zero_()
     size = torch.tensor([8 * hw[0], 8 * hw[1]])
-    (f, _, mf), (b, _, mb) = util.apply_optical_flow(_data(fw, bw, size, 2, dev), None, _args(True, alpha1=a1, alpha2=a2))
+    (f, _, mf), (b, _, mb) = util.apply_optical_flow(_data(fw, bw, size, nfr, dev), None, _args(True, alpha1=a1, alpha2=a2))
     with O.aten_samplers():
         (fo, _, mfo), (bo, _, mbo) = O.apply_optical_flow_file(fw, bw, size, True, a1, a2)
     assert torch.equal(torch.nan_to_num(f.cpu(), nan=123.0), torch.nan_to_num(fo, nan=123.0))
@@ -193,3 +195,32 @@ def test_flow_prepare_adversarial_inputs_vs_oracle(dev, case):
     assert torch.equal(mf.cpu(), mfo) and torch.equal(mb.cpu(), mbo)
     r = util.calc_mask_ratio(mf).cpu()
     assert torch.allclose(r, (~mfo).float().mean((-1, -2)), atol=1e-6, rtol=0)
+
+
+def test_flow_prepare_without_workspace_equals_certified_route(dev):
+    """pixpro_flow_prepare (no workspace: every tile through the staged mask kernel) and pixpro_flow_prepare_ws (block
+    boxes + certified masks) are two routes to the same bits, nframe = 4 at 360x640."""
+    from contrast import util, _native as nv
+    from recipes import smooth_flow
+    gen = torch.Generator().manual_seed(5)
+    N, F1, hw = 3, 3, (45, 80)
+    fw = smooth_flow((N, F1, 2, *hw), 0.3, gen)
+    bw = -fw.flip(1) + smooth_flow((N, F1, 2, *hw), 0.03, gen)
+    size = torch.tensor([8 * hw[0], 8 * hw[1]])
+    (f, _, mf), (b, _, mb) = util.apply_optical_flow(_data(fw, bw, size, F1 + 1, dev), None, _args(True))
+    lo_f, lo_b = fw.to(dev).contiguous(), bw.to(dev).contiguous()
+    f2 = torch.empty_like(f); b2 = torch.empty_like(b)
+    mf2 = torch.empty(mf.shape, dtype=torch.bool, device=dev); mb2 = torch.empty_like(mf2)
+    cnt = torch.empty(2 * N, dtype=torch.int32, device=dev)
+    assert nv.load().pixpro_flow_prepare_workspace_bytes(N, F1, hw[0], hw[1], 1) == 2 * N * hw[0] * hw[1] * 16
+    assert nv.load().pixpro_flow_prepare_workspace_bytes(N, 1, hw[0], hw[1], 1) == 0
+    nv.call("pixpro_flow_prepare", nv.ptr(lo_f), nv.ptr(lo_b), nv.ptr(f2), nv.ptr(b2), nv.ptr(mf2), nv.ptr(mb2),
+            nv.ptr(cnt), N, F1, hw[0], hw[1], 1, 0.01, 0.5, nv.stream())
+    assert torch.equal(f, f2) and torch.equal(b, b2)
+    assert torch.equal(mf.as_subclass(torch.Tensor), mf2) and torch.equal(mb.as_subclass(torch.Tensor), mb2)
+    assert torch.equal(cnt[:N].cpu(), (~mf2).sum((-1, -2)).int().cpu())
+    # a workspace that is too small is refused, not ignored
+    small = torch.empty(64, dtype=torch.uint8, device=dev)
+    with pytest.raises(RuntimeError):
+        nv.call("pixpro_flow_prepare_ws", nv.ptr(lo_f), nv.ptr(lo_b), nv.ptr(f2), nv.ptr(b2), nv.ptr(mf2), nv.ptr(mb2),
+                nv.ptr(cnt), N, F1, hw[0], hw[1], 1, 0.01, 0.5, nv.ptr(small), 64, nv.stream())
