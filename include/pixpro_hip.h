@@ -152,7 +152,7 @@ int pixpro_fbc_mask(const float* flow_fwd, const float* flow_bwd, uint8_t* mask,
  * (nullable) int32 [2*N]: number of invalid pixels per sample (fwd then bwd), the numerator
  * of calc_mask_ratio (util.py:360-366).  F1 == 1 (nframe 2): two launches (flows + certified masks; the tiles the
  * certificate cannot settle), the only HBM traffic is the low-res read and the output write; F1 > 1: one chain launch
- * (up-sampling evaluated lazily) + one mask launch.  Both of ATen's CPU bilinear up-sampling orders are reproduced
+ * (up-sampling evaluated lazily) + one mask launch (see pixpro_flow_prepare_ws for the certified mask route).  Both of ATen's CPU bilinear up-sampling orders are reproduced
  * (switch at 8h + 8w = 128).  No workspace.  The environment variable PIXPRO_FLOW_PATH = auto | certified | staged
  * selects between two bit-identical ways of producing the F1 == 1 masks (a testing / timing knob). */
 int pixpro_flow_prepare(const float* lo_fwd, const float* lo_bwd, float* flow_fwd,
