@@ -216,7 +216,7 @@ __device__ __forceinline__ void gram_tile(f32x4 (&acc)[2][2], const float* __res
   }
 }
 
-// MODE 0: S -> A, D (grid: tiles_n, tiles_m, B).  MODE 1: dSs on tile pairs (grid: pairs, 1, B).
+// MODE 0: S -> A, D on the tiles ti <= tj, mirrored (grid: pairs, 1, B).  MODE 1: dSs on tile pairs (grid: pairs, 1, B).
 template <int MODE>
 __global__ void __launch_bounds__(TB) k_tl_gram(Dirs D, TlWs w, int N, int C, int P, float p, float clampv) {
   __shared__ float As[16 * TSB], Bs[16 * TSB];
@@ -228,7 +228,12 @@ __global__ void __launch_bounds__(TB) k_tl_gram(Dirs D, TlWs w, int N, int C, in
   const pixpro_dir& dd = D.d[b / N];
   const f32x4 z = {0.f, 0.f, 0.f, 0.f};
   if (MODE == 0) {
-    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    // S is symmetric: only the tiles (ti <= tj) are computed (10 of 16 at P = 196) and written twice, the mirror image
+    // as one float4 per lane (four consecutive rows of the accumulator are four consecutive columns of the mirror; P % 4 == 0)
+    const int nt = (P + 63) / 64;
+    int ti = 0, rem = blockIdx.x;
+    while (rem >= nt - ti) { rem -= nt - ti; ++ti; }
+    const int tj = ti + rem, m0 = ti * 64, n0 = tj * 64;
     const float* x = dd.x + (size_t)(b % N) * R;
     f32x4 acc[2][2] = {{z, z}, {z, z}};
     gram_tile(acc, x, x, m0, n0, C, P, As, Bs);
@@ -238,18 +243,24 @@ __global__ void __launch_bounds__(TB) k_tl_gram(Dirs D, TlWs w, int N, int C, in
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const int gn = n0 + wn + 16 * j + lr;
+        const int gn = n0 + wn + 16 * j + lr, gm0 = m0 + wm + 16 * i + 4 * lq;
+        if (gn >= P || gm0 >= P) continue;
+        const float rxn = rx[gn], rvn = rv[gn];
+        float a[4], d[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int gm = m0 + wm + 16 * i + 4 * lq + r;
-          if (gm < P && gn < P) {
-            float a, d;
-            pow_map(acc[i][j][r] * rx[gm] * rx[gn], p, clampv, a, d);
-            w.A[(size_t)b * Q + (size_t)gm * P + gn] = a;
-            w.Dm[(size_t)b * Q + (size_t)gm * P + gn] = d;
-            // the 1/||v|| of Y = v^ A folded into A's rows, so that the strip product stages v as it is
-            w.Av[(size_t)b * Q + (size_t)gm * P + gn] = rv[gm] * a;
-          }
+          const int gm = gm0 + r;
+          pow_map(acc[i][j][r] * rx[gm] * rxn, p, clampv, a[r], d[r]);
+          w.A[(size_t)b * Q + (size_t)gm * P + gn] = a[r];
+          w.Dm[(size_t)b * Q + (size_t)gm * P + gn] = d[r];
+          // the 1/||v|| of Y = v^ A folded into A's rows, so that the strip product stages v as it is
+          w.Av[(size_t)b * Q + (size_t)gm * P + gn] = rv[gm] * a[r];
+        }
+        if (ti != tj) {
+          const size_t o = (size_t)b * Q + (size_t)gn * P + gm0;
+          *reinterpret_cast<float4*>(w.A + o) = make_float4(a[0], a[1], a[2], a[3]);
+          *reinterpret_cast<float4*>(w.Dm + o) = make_float4(d[0], d[1], d[2], d[3]);
+          *reinterpret_cast<float4*>(w.Av + o) = make_float4(rvn * a[0], rvn * a[1], rvn * a[2], rvn * a[3]);
         }
       }
   } else {
@@ -566,7 +577,7 @@ int run_tiled_c(const pixpro_problem& pb, const Dirs& D, const TlWs& w, float* l
   TL_CHECK("k_tl_prep");
   hipLaunchKernelGGL(k_tl_rnorms, dim3(nt, B, 3), dim3(TB), 0, st, D, w.rx, w.rv, w.rk, N, C, P, pb.normalize_k);
   TL_CHECK("k_tl_rnorms");
-  hipLaunchKernelGGL(k_tl_gram<0>, dim3(nt, nt, B), dim3(TB), 0, st, D, w, N, C, P, pb.p, pb.clamp);
+  hipLaunchKernelGGL(k_tl_gram<0>, dim3(nt * (nt + 1) / 2, 1, B), dim3(TB), 0, st, D, w, N, C, P, pb.p, pb.clamp);
   TL_CHECK("k_tl_gram<0>");
   hipLaunchKernelGGL((k_tl_strip<MW, 0>), dim3(nt, B, 1), dim3(TB), 0, st, pb, D, w, g0, (int)want_grad);
   TL_CHECK("k_tl_strip<0>");
