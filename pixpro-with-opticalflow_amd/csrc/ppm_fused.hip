@@ -233,6 +233,85 @@ __device__ __forceinline__ void col_reduce_reg(float (&v)[NT], float* part) {
   }
 }
 
+// The same with one more column (the 49th of the 7 x 7 grid, kept outside the MFMA tile grid): `ve` is this lane's partial
+// for it (0 in lanes that hold none) and comes back as its total in every lane.  Slot 48 of a wave's slice is free
+// because NT = 3 column tiles use slots 0..47.
+template <int NT>
+__device__ __forceinline__ void col_reduce_edge(float (&v)[NT], float& ve, float* part) {
+  static_assert(NT == 3, "slot 48 is the first free one");
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, lr = lane & 15;
+  const float se = wave_sum(ve);
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    float s = v[n];
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    if (lane < 16) part[wave * 64 + 16 * n + lane] = s;
+  }
+  if (lane == 0) part[wave * 64 + 48] = se;
+  __syncthreads();
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < NWAVES; ++w) t += part[w * 64 + 16 * n + lr];
+    v[n] = t;
+  }
+  float te = 0.f;
+#pragma unroll
+  for (int w = 0; w < NWAVES; ++w) te += part[w * 64 + 48];
+  ve = te;
+}
+
+// Column 48 of a C x P product on the vector ALU: e(c) = sum_{k < 49} A[c][k] w[k] for the wave's 16 MT rows.  Lane l
+// takes row (l & 31) of the wave's row list and half of k (l >> 5).  w[k] = scale[k] * B[k][48] is written by lane k
+// into the wave's own 64-float LDS slice `ws` first (same wave writes and reads: no barrier), so one k costs two LDS
+// reads (both pair up with their neighbours) and one FMA.  Returns e in lanes 0..31 (duplicated in 32..63).
+template <int MT>
+__device__ __forceinline__ float edge_column(const float* __restrict__ tile, int P, float wl, float* __restrict__ ws) {
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int rl = lane & 31, hi = lane >> 5;
+  const int row = 16 * (wave + NWAVES * min(rl >> 4, MT - 1)) + (rl & 15);
+  ws[lane] = wl;                            // lanes >= 49 pass 0
+  const float* a = tile + row * P + 25 * hi;
+  const float* w = ws + 25 * hi;
+  float e0 = 0.f, e1 = 0.f;
+#pragma unroll
+  for (int k = 0; k < 24; k += 2) {
+    e0 = __builtin_fmaf(a[k], w[k], e0);
+    e1 = __builtin_fmaf(a[k + 1], w[k + 1], e1);
+  }
+  e0 = __builtin_fmaf(hi ? 0.f : a[24], w[24], e0);     // k = 24: lower half only (the upper half ends at 48 = 25 + 23)
+  float e = e0 + e1;
+  e += __shfl_xor(e, 32, 64);
+  if (MT == 1 && rl >= 16) e = 0.f;         // one row tile per wave: lanes 16..31 duplicate it
+  return e;
+}
+// The same for G = k_hat M^T: w[k] = M[48][k] / ||k_k|| is zero except for the few positive pairs of row 48, so the
+// loop runs over the set bits of the row (wave-uniform) - two LDS reads and one FMA per positive.
+template <int MT>
+__device__ __forceinline__ float edge_column_bits(const float* __restrict__ tile, int P, unsigned long long bits,
+                                                  const float* __restrict__ rk) {
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int rl = lane & 31;
+  const int row = 16 * (wave + NWAVES * min(rl >> 4, MT - 1)) + (rl & 15);
+  const float* a = tile + row * P;
+  unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)bits), hi = __builtin_amdgcn_readfirstlane((unsigned)(bits >> 32));
+  float e0 = 0.f, e1 = 0.f;
+  while (lo | hi) {
+    int k;
+    if (lo) { k = __builtin_ctz(lo); lo &= lo - 1; } else { k = 32 + __builtin_ctz(hi); hi &= hi - 1; }
+    e0 = __builtin_fmaf(a[k], rk[k], e0);
+    if (lo | hi) {
+      if (lo) { k = __builtin_ctz(lo); lo &= lo - 1; } else { k = 32 + __builtin_ctz(hi); hi &= hi - 1; }
+      e1 = __builtin_fmaf(a[k], rk[k], e1);
+    }
+  }
+  float e = e0 + e1;
+  if (MT == 1 && rl >= 16) e = 0.f;
+  return e;
+}
+
 // C x P contraction: acc[m][n] += sum_k Aop(m, k) * Bop(n, k), k in steps of 4.  Software-pipelined by hand: the
 // operands of step k+1 are requested from LDS before the MFMAs of step k issue (hipcc otherwise places every ds_read
 // right in front of its consumer with an lgkmcnt(0) wait).
@@ -661,24 +740,37 @@ ppm_fused_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* _
   STAMP(4);
 
   // ---- Y = v_hat A ----
-  f32x4 Y[MT][NT];
+  // 7 x 7 grid: the four C x P products run on NTM = 3 column tiles (48 columns); column 48 is a vector-ALU dot product
+  // per row (edge_column), held one value per lane (lanes 0..31 = the wave's rows) next to the accumulators.
+  constexpr bool EDGE = PC == 49;
+  constexpr int NTM = EDGE ? 3 : NT;
+  const bool elive = lane < 16 * MT;                      // lanes that own an edge value
+  const int erow = 16 * (wave + NWAVES * min((lane & 31) >> 4, MT - 1)) + (lane & 15);   // ... and its row
+  f32x4 Y[MT][NTM];
 #pragma unroll
   for (int m = 0; m < MT; ++m)
 #pragma unroll
-    for (int nn = 0; nn < NT; ++nn) Y[m][nn] = zero4;
+    for (int nn = 0; nn < NTM; ++nn) Y[m][nn] = zero4;
   // k index j >= P reads the next row / the zeroed pad: finite, times a zero B row
-  gemm_cp<MT, NT>(Y, KS,
-                  [&](int m, int ks) { return sm.B1[arow(m) * P + 4 * ks + lq]; },
-                  [&](int ks) { return sm.rv[4 * ks + lq]; },
-                  [&](int nn, int ks) { return sm.AA[(4 * ks + lq) * LS + 16 * nn + lr]; });
+  gemm_cp<MT, NTM>(Y, KS,
+                   [&](int m, int ks) { return sm.B1[arow(m) * P + 4 * ks + lq]; },
+                   [&](int ks) { return sm.rv[4 * ks + lq]; },
+                   [&](int nn, int ks) { return sm.AA[(4 * ks + lq) * LS + 16 * nn + lr]; });
+  float Ye = 0.f;
+  if constexpr (EDGE) Ye = edge_column<MT>(sm.B1, P, lane < P ? sm.rv[lane] * sm.AA[lane * LS + (P - 1)] : 0.f, sm.part0 + wave * 64);
   STAMP(5);
   // Column norms of Y and of k with two barriers.  Y stays raw in its registers (its 1 / ||.|| enters the loss dot product
   // and dY as per-column factors); every wave keeps its own copy of 1 / ||k_j|| in its slice of part1, so that no third
   // barrier is needed to publish it.
-  float ry[NT];      // 1 / ||Y[:, i]|| of this lane's columns
+  float ry[NTM];     // 1 / ||Y[:, i]|| of this lane's columns
+  float rye = 0.f;   // ... and of column 48
   {
+    if constexpr (EDGE) {
+      const float qe = wave_sum(elive ? Ye * Ye : 0.f);
+      if (lane == 0) sm.part1[wave * 64 + 48] = qe;
+    }
 #pragma unroll
-    for (int nn = 0; nn < NT; ++nn) {
+    for (int nn = 0; nn < NTM; ++nn) {
       float q = 0.f;
 #pragma unroll
       for (int m = 0; m < MT; ++m)
@@ -703,11 +795,17 @@ ppm_fused_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* _
       sm.part0[wave * 64 + lane] = a0 + a1;
     }
 #pragma unroll
-    for (int nn = 0; nn < NT; ++nn) {
+    for (int nn = 0; nn < NTM; ++nn) {
       float t = 0.f;
 #pragma unroll
       for (int w = 0; w < NWAVES; ++w) t += sm.part1[w * 64 + 16 * nn + lr];
       ry[nn] = 1.f / fmaxf(sqrtf(t), 1e-12f);
+    }
+    if constexpr (EDGE) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < NWAVES; ++w) t += sm.part1[w * 64 + 48];
+      rye = 1.f / fmaxf(sqrtf(t), 1e-12f);
     }
     __syncthreads();
     float rkj = 1.f;
@@ -724,43 +822,48 @@ ppm_fused_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* _
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-      for (int nn = 0; nn < NT; ++nn)
+      for (int nn = 0; nn < NTM; ++nn)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int i = 16 * nn + lr;
           if (i < P) gp[nhwc ? (size_t)i * C + crow(m, r) : (size_t)crow(m, r) * P + i] = Y[m][nn][r] * ry[nn];
         }
+    if (EDGE && elive) gp[nhwc ? (size_t)(P - 1) * C + erow : (size_t)erow * P + (P - 1)] = Ye * rye;
   }
   STAMP(6);
 
   // ---- G = k_hat M^T ----
-  f32x4 G[MT][NT];
+  f32x4 G[MT][NTM];
+  float Ge = 0.f;
 #pragma unroll
   for (int m = 0; m < MT; ++m)
 #pragma unroll
-    for (int nn = 0; nn < NT; ++nn) G[m][nn] = zero4;
+    for (int nn = 0; nn < NTM; ++nn) G[m][nn] = zero4;
   {
     // row bits pre-shifted by the lane's k offset: bit 4*ks of the low / high word is M[i][4*ks + lq]
-    unsigned lo[NT], hi[NT];
+    unsigned lo[NTM], hi[NTM];
 #pragma unroll
-    for (int nn = 0; nn < NT; ++nn) {
+    for (int nn = 0; nn < NTM; ++nn) {
       const unsigned long long rb = sm.mbits[16 * nn + lr] >> lq;
       lo[nn] = (unsigned)rb; hi[nn] = (unsigned)(rb >> 32);
     }
-    gemm_cp<MT, NT>(G, KS,
-                    [&](int m, int ks) { return sm.B0[arow(m) * P + 4 * ks + lq]; },
-                    [&](int ks) { return sm.part1[wave * 64 + 4 * ks + lq]; },
-                    [&](int nn, int ks) {
-                      const unsigned w = ks < 8 ? lo[nn] : hi[nn];
-                      return (float)((w >> ((4 * ks) & 31)) & 1u);
-                    });
+    gemm_cp<MT, NTM>(G, KS,
+                     [&](int m, int ks) { return sm.B0[arow(m) * P + 4 * ks + lq]; },
+                     [&](int ks) { return sm.part1[wave * 64 + 4 * ks + lq]; },
+                     [&](int nn, int ks) {
+                       const unsigned w = ks < 8 ? lo[nn] : hi[nn];
+                       return (float)((w >> ((4 * ks) & 31)) & 1u);
+                     });
+    if constexpr (EDGE)                     // row 48 of M against the wave's own copy of 1 / ||k||
+      Ge = edge_column_bits<MT>(sm.B0, P, sm.mbits[P - 1] & ((1ull << P) - 1), sm.part1 + wave * 64);
   }
   STAMP(7);
-  float tc[NT];      // <Y_hat[:, i], G[:, i]> of this lane's columns (Y raw in registers: ry applied after the reduction)
+  float tc[NTM];     // <Y_hat[:, i], G[:, i]> of this lane's columns (Y raw in registers: ry applied after the reduction)
+  float tce = 0.f;
   {
-    float v[NT];
+    float v[NTM];
 #pragma unroll
-    for (int nn = 0; nn < NT; ++nn) {
+    for (int nn = 0; nn < NTM; ++nn) {
       float s = 0.f;
 #pragma unroll
       for (int m = 0; m < MT; ++m)
@@ -768,17 +871,24 @@ ppm_fused_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* _
         for (int r = 0; r < 4; ++r) s = __builtin_fmaf(Y[m][nn][r], G[m][nn][r], s);
       v[nn] = s;
     }
-    col_reduce_reg<NT>(v, sm.part1);       // a wave overwrites only its own slice (its 1 / ||k|| copy, no longer needed);
-                                           // barrier: every wave is done reading k from B0
+    // a wave overwrites only its own slice (its 1 / ||k|| copy, no longer needed); barrier: every wave is done reading k
+    if constexpr (EDGE) {
+      float ve = elive ? Ye * Ge : 0.f;
+      col_reduce_edge<NTM>(v, ve, sm.part1);
+      tce = ve * rye;
+    } else {
+      col_reduce_reg<NTM>(v, sm.part1);
+    }
 #pragma unroll
-    for (int nn = 0; nn < NT; ++nn) tc[nn] = v[nn] * ry[nn];
+    for (int nn = 0; nn < NTM; ++nn) tc[nn] = v[nn] * ry[nn];
   }
   const float cnt = sm.misc[1];
   const float den = cnt + 1e-6f;
   if (wave == 0) {
     float t = 0.f;
 #pragma unroll
-    for (int nn = 0; nn < NT; ++nn) t += (lane < 16 && 16 * nn + lr < P) ? tc[nn] : 0.f;
+    for (int nn = 0; nn < NTM; ++nn) t += (lane < 16 && 16 * nn + lr < P) ? tc[nn] : 0.f;
+    if (EDGE && lane == 0) t += tce;
     t = wave_sum(t);
     if (lane == 0) {
       loss_n[b] = t / den;
@@ -793,8 +903,9 @@ ppm_fused_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* _
   LOAD_TILE(pfa, gx);
   {
     const float gs = pb.grad_scale * -2.f / (float)N / den;
+    if (EDGE && elive) sm.B0[erow * P + (P - 1)] = __builtin_fmaf(-Ye, rye * rye * (gs * tce), Ge * (gs * rye));
 #pragma unroll
-    for (int nn = 0; nn < NT; ++nn) {
+    for (int nn = 0; nn < NTM; ++nn) {
       const int i = 16 * nn + lr;
       if (i < P) {
         // (gs G - Y_hat ti) ry with Y_hat = Y ry, ti = gs <Y_hat, G>:  G (gs ry) - Y (ry ry ti)
@@ -840,19 +951,25 @@ ppm_fused_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* _
 
   // ---- dV_hat = dY A ; dv = (dV_hat - v_hat s) / n_v ----
   {
-    f32x4 T[MT][NT];
+    f32x4 T[MT][NTM];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-      for (int nn = 0; nn < NT; ++nn) T[m][nn] = zero4;
-    gemm_cp<MT, NT>(T, KS,
-                    [&](int m, int ks) { return sm.B0[arow(m) * P + 4 * ks + lq]; },
-                    [&](int) { return 1.f; },
-                    [&](int nn, int ks) { return sm.AA[(4 * ks + lq) * LS + 16 * nn + lr]; });
-    float vh[MT][NT][4];
-    float v[NT];
+      for (int nn = 0; nn < NTM; ++nn) T[m][nn] = zero4;
+    gemm_cp<MT, NTM>(T, KS,
+                     [&](int m, int ks) { return sm.B0[arow(m) * P + 4 * ks + lq]; },
+                     [&](int) { return 1.f; },
+                     [&](int nn, int ks) { return sm.AA[(4 * ks + lq) * LS + 16 * nn + lr]; });
+    float Te = 0.f, ve = 0.f, ves = 0.f;     // column 48: product, raw v, partial of the projection dot product
+    if constexpr (EDGE) {
+      Te = edge_column<MT>(sm.B0, P, lane < P ? sm.AA[lane * LS + (P - 1)] : 0.f, sm.part1 + wave * 64);
+      ve = sm.B1[erow * P + (P - 1)];
+      ves = elive ? ve * Te * sm.rv[P - 1] : 0.f;
+    }
+    float vh[MT][NTM][4];
+    float v[NTM];
 #pragma unroll
-    for (int nn = 0; nn < NT; ++nn) {
+    for (int nn = 0; nn < NTM; ++nn) {
       const int j = 16 * nn + lr;
       float s = 0.f;
       const float rvj = sm.rv[min(j, P - 1)];
@@ -865,10 +982,11 @@ ppm_fused_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* _
         }
       v[nn] = s * rvj;
     }
-    col_reduce_reg<NT>(v, sm.part0);         // barrier: every wave is done reading dY from B0
+    // barrier inside: every wave is done reading dY from B0
+    if constexpr (EDGE) col_reduce_edge<NTM>(v, ves, sm.part0); else col_reduce_reg<NTM>(v, sm.part0);
     PUT_TILE(pfa, sm.B0);                    // x -> B0 (second read)
 #pragma unroll
-    for (int nn = 0; nn < NT; ++nn) {
+    for (int nn = 0; nn < NTM; ++nn) {
       const int j = 16 * nn + lr;
       if (j < P) {
         const float rvj = sm.rv[j], cj = rvj * rvj * v[nn];      // (T - v_hat s) rv = T rv - v (rv rv s)
@@ -878,6 +996,10 @@ ppm_fused_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* _
           for (int r = 0; r < 4; ++r) sm.B1[crow(m, r) * P + j] = __builtin_fmaf(-vh[m][nn][r], cj, T[m][nn][r] * rvj);
       }
     }
+    if (EDGE && elive) {
+      const float rve = sm.rv[P - 1];
+      sm.B1[erow * P + (P - 1)] = __builtin_fmaf(-ve, rve * rve * ves, Te * rve);
+    }
   }
   __syncthreads();
   STAMP(12);
@@ -886,19 +1008,25 @@ ppm_fused_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* _
 
   // ---- dX_hat = x_hat dSs ; dx = (dX_hat - x_hat s) / n_x ----
   {
-    f32x4 T[MT][NT];
+    f32x4 T[MT][NTM];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-      for (int nn = 0; nn < NT; ++nn) T[m][nn] = zero4;
-    gemm_cp<MT, NT>(T, KS,
-                    [&](int m, int ks) { return sm.B0[arow(m) * P + 4 * ks + lq]; },
-                    [&](int ks) { return sm.rx[4 * ks + lq]; },
-                    [&](int nn, int ks) { return sm.Dm[(4 * ks + lq) * LS + 16 * nn + lr]; });
-    float xh[MT][NT][4];
-    float v[NT];
+      for (int nn = 0; nn < NTM; ++nn) T[m][nn] = zero4;
+    gemm_cp<MT, NTM>(T, KS,
+                     [&](int m, int ks) { return sm.B0[arow(m) * P + 4 * ks + lq]; },
+                     [&](int ks) { return sm.rx[4 * ks + lq]; },
+                     [&](int nn, int ks) { return sm.Dm[(4 * ks + lq) * LS + 16 * nn + lr]; });
+    float Te = 0.f, xe = 0.f, xes = 0.f;
+    if constexpr (EDGE) {
+      Te = edge_column<MT>(sm.B0, P, lane < P ? sm.rx[lane] * sm.Dm[lane * LS + (P - 1)] : 0.f, sm.part0 + wave * 64);
+      xe = sm.B0[erow * P + (P - 1)];
+      xes = elive ? xe * Te * sm.rx[P - 1] : 0.f;
+    }
+    float xh[MT][NTM][4];
+    float v[NTM];
 #pragma unroll
-    for (int nn = 0; nn < NT; ++nn) {
+    for (int nn = 0; nn < NTM; ++nn) {
       const int j = 16 * nn + lr;
       float s = 0.f;
       const float rxj = sm.rx[min(j, P - 1)];
@@ -911,9 +1039,10 @@ ppm_fused_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* _
         }
       v[nn] = s * rxj;
     }
-    col_reduce_reg<NT>(v, sm.part1);         // barrier: every wave is done reading x from B0
+    // barrier inside: every wave is done reading x from B0
+    if constexpr (EDGE) col_reduce_edge<NTM>(v, xes, sm.part1); else col_reduce_reg<NTM>(v, sm.part1);
 #pragma unroll
-    for (int nn = 0; nn < NT; ++nn) {
+    for (int nn = 0; nn < NTM; ++nn) {
       const int j = 16 * nn + lr;
       if (j < P) {
         const float rxj = sm.rx[j], cj = rxj * rxj * v[nn];
@@ -922,6 +1051,10 @@ ppm_fused_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* _
 #pragma unroll
           for (int r = 0; r < 4; ++r) sm.B0[crow(m, r) * P + j] = __builtin_fmaf(-xh[m][nn][r], cj, T[m][nn][r] * rxj);
       }
+    }
+    if (EDGE && elive) {
+      const float rxe = sm.rx[P - 1];
+      sm.B0[erow * P + (P - 1)] = __builtin_fmaf(-xe, rxe * rxe * xes, Te * rxe);
     }
   }
   __syncthreads();
