@@ -444,7 +444,8 @@ def main():
     model.train()
 
     from contrast import _native
-    clock = KernelClock({"pixpro_flow_prepare": "flow_prepare", "pixpro_ppm_loss": "ppm_loss",
+    clock = KernelClock({"pixpro_flow_prepare": "flow_prepare", "pixpro_flow_prepare_ws": "flow_prepare",
+                         "pixpro_ppm_loss": "ppm_loss",
                          "pixpro_lars_sgd_step": "lars_sgd_step", "pixpro_ema_update": "ema_update"})
     clock.install(_native)
 
