@@ -487,6 +487,8 @@ k_prepare_cert(const float* __restrict__ lo_fwd, const float* __restrict__ lo_bw
   float4 t0 = make_float4(0.f, 0.f, 0.f, 0.f), t1 = t0, bxf = t0, bxb = t0;   // bxf: bwd-flow box for fwd pixels
   int have = -2, badf = 0, badb = 0;                           // bad counts are wave-uniform
   unsigned undecided = 0;                                      // bit 2*rr + d: inside the frame but not certified
+  bool cellok[2] = {false, false};                             // both directions certified for the current run of rows
+  bool allok = false;                                          // ... in every lane of the wave
   float* of = flow_fwd + (size_t)n * 2 * HW + x;
   float* ob = flow_bwd + (size_t)n * 2 * HW + x;
   const int yw = ty0 + wave * ROWS_C;
@@ -509,8 +511,37 @@ k_prepare_cert(const float* __restrict__ lo_fwd, const float* __restrict__ lo_bw
       if (certify) {
         const int ci = (ay.i0 - wy0) * W0_W + cxi;
         bxf = tab[0][ci]; bxb = tab[1][ci];
+        // Certificate for ALL rows of this lane that share the cell row (at most 9): between the two x-interpolated
+        // source rows the column pass is a convex combination, so the lane's own flow stays in [min(t0,t1), max(t0,t1)]
+        // per channel; with the box of the opposite flow that bounds |fn + b'| for the whole run of rows, and the first /
+        // last possible row bound the position.  Where it holds (smooth flow: almost everywhere) the rows below cost the
+        // up-sampling and the stores only.
+        const float cya = div_c(2.f * (float)y, g.ht) - 1.f, cyb = div_c(2.f * (float)min(y + 9, g.Hf - 1), g.ht) - 1.f;
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          const float ax_ = d ? t0.z : t0.x, bx_ = d ? t1.z : t1.x, ay_ = d ? t0.w : t0.y, by_ = d ? t1.w : t1.y;
+          float fLx, fUx, fLy, fUy;
+          norm_box(fminf(ax_, bx_), fmaxf(ax_, bx_), g.wd, fLx, fUx);
+          norm_box(fminf(ay_, by_), fmaxf(ay_, by_), g.ht, fLy, fUy);
+          const float4 bx = d ? bxb : bxf;
+          const bool in_all = (c0x + fLx > -1.f) && (c0x + fUx < 1.f) && (cya + fLy > -1.f) && (cyb + fUy < 1.f);
+          const float mx = fmaxf(fabsf(fLx + bx.x), fabsf(fUx + bx.y));
+          const float my = fmaxf(fabsf(fLy + bx.z), fabsf(fUy + bx.w));
+          cellok[d] = in_all && (__builtin_fmaf(mx, mx, my * my) <= a2c);      // false for NaN
+        }
+        allok = __all(cellok[0] && cellok[1]) != 0;            // the rows of a wave change cell rows together
       }
       have = ay.i0;
+    }
+    if (allok) {                                               // wave-uniform: flows and two constant mask bytes
+      if (act) {
+        const size_t q = (size_t)y * g.Wf;
+        of[q] = 8.f * up8_col(t0.x, t1.x, ay.l0, ay.l1); of[HW + q] = 8.f * up8_col(t0.y, t1.y, ay.l0, ay.l1);
+        ob[q] = 8.f * up8_col(t0.z, t1.z, ay.l0, ay.l1); ob[HW + q] = 8.f * up8_col(t0.w, t1.w, ay.l0, ay.l1);
+        mask_fwd[(size_t)n * HW + q + x] = 1;
+        mask_bwd[(size_t)n * HW + q + x] = 1;
+      }
+      continue;
     }
     // 16 * (interpolated value) = 2 * upflow8 value; both scalings are exact
     const float fx16 = 16.f * up8_col(t0.x, t1.x, ay.l0, ay.l1), fy16 = 16.f * up8_col(t0.y, t1.y, ay.l0, ay.l1);
@@ -521,19 +552,22 @@ k_prepare_cert(const float* __restrict__ lo_fwd, const float* __restrict__ lo_bw
       ob[q] = 0.5f * bx16; ob[HW + q] = 0.5f * by16;
     }
     if (!certify) continue;                                    // block-uniform
-    const float c0y = div_c(2.f * (float)y, g.ht) - 1.f;
-    const float fn[2][2] = {{div_c(fx16, g.wd), div_c(fy16, g.ht)}, {div_c(bx16, g.wd), div_c(by16, g.ht)}};
-    bool ok[2];
+    bool ok[2] = {true, true};
+    if (!(cellok[0] && cellok[1])) {                           // the per-pixel certificate, where the run of rows failed
+      const float c0y = div_c(2.f * (float)y, g.ht) - 1.f;
+      const float fn[2][2] = {{div_c(fx16, g.wd), div_c(fy16, g.ht)}, {div_c(bx16, g.wd), div_c(by16, g.ht)}};
 #pragma unroll
-    for (int d = 0; d < 2; ++d) {
-      const float4 bx = d ? bxb : bxf;
-      const float c1x = c0x + fn[d][0], c1y = c0y + fn[d][1];
-      const bool inside = (fabsf(c1x) < 1.f) && (fabsf(c1y) < 1.f);
-      const float mx = fmaxf(fabsf(fn[d][0] + bx.x), fabsf(fn[d][0] + bx.y));
-      const float my = fmaxf(fabsf(fn[d][1] + bx.z), fabsf(fn[d][1] + bx.w));
-      const bool sure = __builtin_fmaf(mx, mx, my * my) <= a2c;
-      ok[d] = inside && sure;
-      if (inside && !sure) undecided |= 1u << (2 * rr + d);   // settled exactly after the loop
+      for (int d = 0; d < 2; ++d) {
+        if (cellok[d]) continue;
+        const float4 bx = d ? bxb : bxf;
+        const float c1x = c0x + fn[d][0], c1y = c0y + fn[d][1];
+        const bool inside = (fabsf(c1x) < 1.f) && (fabsf(c1y) < 1.f);
+        const float mx = fmaxf(fabsf(fn[d][0] + bx.x), fabsf(fn[d][0] + bx.y));
+        const float my = fmaxf(fabsf(fn[d][1] + bx.z), fabsf(fn[d][1] + bx.w));
+        const bool sure = __builtin_fmaf(mx, mx, my * my) <= a2c;
+        ok[d] = inside && sure;
+        if (inside && !sure) undecided |= 1u << (2 * rr + d);   // settled exactly after the loop
+      }
     }
     if (act) {
       mask_fwd[(size_t)n * HW + q + x] = ok[0] ? 1 : 0;

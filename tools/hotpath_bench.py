@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--flow-offset", type=float, default=0.0, help="constant added to the forward flow's x component (full-res "
                                                                     "pixels; the backward flow gets the negative): coherent motion")
     ap.add_argument("--flow-step", type=float, default=0.0, help="motion boundary: this many pixels added right of the middle")
+    ap.add_argument("--no-mask", action="store_true", help="flow preparation without the consistency masks (alpha None)")
     ap.add_argument("--lib", default=None, help="load this build of libpixpro_hip.so instead of the in-tree one (kernel variants)")
     ap.add_argument("--channels-last", action="store_true", help="feature maps in channels_last memory format (bench default)")
     a = ap.parse_args()
@@ -50,7 +51,7 @@ def main():
         lo_f[:, :, 0] += a.flow_offset / 8.0; lo_b[:, :, 0] -= a.flow_offset / 8.0
         half = lo_f.shape[-1] // 2
         lo_f[:, :, 0, :, half:] += a.flow_step / 8.0; lo_b[:, :, 0, :, half:] -= a.flow_step / 8.0
-    args = types.SimpleNamespace(alpha1=0.01, alpha2=0.5, use_flow_frames=False, use_flow_file=True, flow_up=True,
+    args = types.SimpleNamespace(alpha1=None if a.no_mask else 0.01, alpha2=None if a.no_mask else 0.5, use_flow_frames=False, use_flow_file=True, flow_up=True,
                                  flow_cat_norm=False, debug=False)
     A = 720 * 1280 * 4
     F1 = a.n_frames - 1
