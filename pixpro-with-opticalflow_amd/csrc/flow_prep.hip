@@ -971,6 +971,7 @@ k_fbc_cert_dense(const float* __restrict__ flow_fwd, const float* __restrict__ f
   __shared__ float4 ow[2][WBH * WBW];      // opposite-direction boxes around where the tile lands, per direction
   __shared__ float4 tmp[2][WBH * TBX];     // row pass
   __shared__ float4 tab[2][TBY * TBX];     // per own block: normalised, inflated box {Lx, Ux, Ly, Uy} of the opposite flow
+  __shared__ float4 own[2][TBY * TBX];     // the tile's own boxes (raw pixels), per direction
   __shared__ float part0[2][4];            // {min x, max x, min y, max y} of the tile's own flow, per direction
   __shared__ int wide_boxes;
   const int n = blockIdx.z, t = threadIdx.x, lane = t & 63;
@@ -989,6 +990,7 @@ k_fbc_cert_dense(const float* __restrict__ flow_fwd, const float* __restrict__ f
     if (e < TBY * TBX) {
       const int r = e / TBX, c = e - r * TBX;
       if (r < urows && c < ucols) m = bbd[d][(size_t)(by0 + r) * Wb + bx0 + c];
+      own[d][e] = m;
     }
     m.x = wave_min(m.x); m.y = wave_max(m.y); m.z = wave_min(m.z); m.w = wave_max(m.w);
     if (lane == 0) { tmp[0][wave] = m; }
@@ -1079,6 +1081,11 @@ k_fbc_cert_dense(const float* __restrict__ flow_fwd, const float* __restrict__ f
   unsigned undecided = 0;
   const int yw = ty0 + wave * ROWS_C;
   float4 bxf = make_float4(0.f, 0.f, 0.f, 0.f), bxb = bxf;
+  // Certificate for a whole 8 x 8 block from its OWN box: the own flow of its 64 pixels lies in that box, their positions
+  // between the block's first and last column / row; if the bound holds for the extremes, the block's mask bytes are 1
+  // and its 16 B / pixel of flow are never read.
+  const float cxa = div_c(2.f * (float)(tx0 + 8 * bj), g.wd) - 1.f, cxb = div_c(2.f * (float)(tx0 + 8 * bj + 7), g.wd) - 1.f;
+  bool allok = false;
 #pragma unroll 4
   for (int rr = 0; rr < ROWS_C; ++rr) {
     const int y = yw + rr;
@@ -1086,8 +1093,27 @@ k_fbc_cert_dense(const float* __restrict__ flow_fwd, const float* __restrict__ f
     if ((rr & 7) == 0) {
       const int ci = ((y - ty0) >> 3) * TBX + bj;
       bxf = tab[0][ci]; bxb = tab[1][ci];
+      const float cya = div_c(2.f * (float)y, g.ht) - 1.f, cyb = div_c(2.f * (float)(y + 7), g.ht) - 1.f;
+      bool bok = true;
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+        const float4 o = own[d][ci], bx = d ? bxb : bxf;
+        float fLx, fUx, fLy, fUy;
+        norm_box_dense(o.x, o.y, g.wd, fLx, fUx);
+        norm_box_dense(o.z, o.w, g.ht, fLy, fUy);
+        const bool in_all = (cxa + fLx > -1.f) && (cxb + fUx < 1.f) && (cya + fLy > -1.f) && (cyb + fUy < 1.f);
+        const float mx = fmaxf(fabsf(fLx + bx.x), fabsf(fUx + bx.y));
+        const float my = fmaxf(fabsf(fLy + bx.z), fabsf(fUy + bx.w));
+        bok = bok && in_all && (__builtin_fmaf(mx, mx, my * my) <= a2c);       // false for NaN / inf
+      }
+      allok = __all(bok) != 0;
     }
     const size_t q = (size_t)y * g.Wf;
+    if (allok) {                                          // wave-uniform
+      mask_fwd[(size_t)n * HW + q + x] = 1;
+      mask_bwd[(size_t)n * HW + q + x] = 1;
+      continue;
+    }
     const float c0y = div_c(2.f * (float)y, g.ht) - 1.f;
     const float fn[2][2] = {{div_c(2.f * ff[q], g.wd), div_c(2.f * ff[HW + q], g.ht)},
                             {div_c(2.f * fb[q], g.wd), div_c(2.f * fb[HW + q], g.ht)}};
