@@ -72,6 +72,47 @@ def test_ema_matches_oracle(dev):
         assert torch.equal(a.cpu(), b)
 
 
+def test_multi_tensor_chunk_walk_edge_sizes(dev):
+    """The chunked walk of the multi-tensor kernels (16 K-element chunks from an in-kernel prefix table): sizes around the
+    chunk and float4 boundaries, many tiny tensors, a tensor of several chunks, and views that start at an odd element
+    (scalar path) - EMA bit for bit against the oracle, LARS + SGD against it within the order of the norm sums."""
+    from contrast.multi_tensor import ema_update, LarsSgdStep
+    from oracle import pixpro_oracle as O
+    gen = torch.Generator().manual_seed(3)
+    sizes = [1, 2, 3, 4, 5, 255, 16383, 16384, 16385, 32768, 50001, 3 * 16384 + 7] + [7] * 180 + [64] * 120
+    pq = [torch.randn(n, generator=gen) for n in sizes]
+    pk = [torch.randn(n, generator=gen) for n in sizes]
+    flat_q, flat_k = torch.randn(20011, generator=gen), torch.randn(20011, generator=gen)
+    dq = [t.to(dev) for t in pq] + [flat_q.to(dev)[1:], flat_q.to(dev)[3:16390]]       # storage offsets 1 and 3: unaligned
+    dk = [t.to(dev) for t in pk] + [flat_k.to(dev)[1:].clone(), flat_k.to(dev)[3:16390].clone()]
+    base = torch.empty(20011 + 16390, device=dev)
+    dk[-2] = base[1:20011].copy_(flat_k.to(dev)[1:])                                   # views into one buffer at odd offsets
+    dk[-1] = base[20011 + 3:20011 + 16390].copy_(flat_k.to(dev)[3:16390])
+    hq = pq + [flat_q[1:], flat_q[3:16390]]
+    hk = pk + [flat_k[1:], flat_k[3:16390]]
+    m = O.momentum_coefficient(0.99, 77, 8750)
+    want = O.momentum_update(hq, hk, m)
+    ema_update(dq, dk, m)
+    for i, (a, b) in enumerate(zip(dk, want)):
+        assert torch.equal(a.cpu(), b), (i, a.numel())
+    # LARS: every third tensor 1-D-style (no decay, no adaptation)
+    ps = [torch.nn.Parameter(t.to(dev).clone()) for t in pq]
+    wds = [0.0 if i % 3 == 0 else 1e-4 for i in range(len(ps))]
+    ads = [i % 3 != 0 for i in range(len(ps))]
+    step = LarsSgdStep(ps, wds, ads, momentum=0.9)
+    ref_p = [t.clone() for t in pq]
+    ref_b = [None] * len(ps)
+    for it in range(2):
+        gs = [torch.randn(n, generator=gen) for n in sizes]
+        for p_, g_ in zip(ps, gs):
+            p_.grad = g_.to(dev)
+        step.step(0.3)
+        for i in range(len(ps)):
+            ref_p[i], ref_b[i] = O.lars_sgd_step(ref_p[i], gs[i], ref_b[i], 0.3, 0.9, wds[i], ads[i])
+        for i, p_ in enumerate(ps):
+            assert torch.allclose(p_.detach().cpu(), ref_p[i], rtol=3e-6, atol=1e-7), (it, i, sizes[i])
+
+
 def test_lars_golden_trajectory(dev):
     from contrast.lars import LARS, add_weight_decay
     g = load_golden("lars")
