@@ -877,19 +877,16 @@ __device__ __attribute__((noinline)) bool fbc_dense_generic(const float* f, cons
   return fbc_pixel(f[r], f[HW + r], FetchDense{o, o + HW, Wf}, Hf, Wf, y, x, alpha1, a2, 0, cx, cy);
 }
 
-__global__ void __launch_bounds__(NT)
-k_fbc_pair(const float* __restrict__ flow_fwd, const float* __restrict__ flow_bwd, uint8_t* __restrict__ mask_fwd,
-           uint8_t* __restrict__ mask_bwd, int32_t* __restrict__ invalid, int N, Up8Geom g, int marked_only) {
-  __shared__ float2 no[RH * RW];           // normalised opposite flow over the region
-  __shared__ float red[NWAVE][3];
-  const int n = blockIdx.z >> 1, dir = blockIdx.z & 1, t = threadIdx.x;
+__device__ __forceinline__ void fbc_pair_tile(const float* __restrict__ flow_fwd, const float* __restrict__ flow_bwd,
+                                              uint8_t* __restrict__ mask_fwd, uint8_t* __restrict__ mask_bwd,
+                                              int32_t* __restrict__ invalid, int N, const Up8Geom& g, int bx, int by, int n,
+                                              int dir, float2* __restrict__ no, float (*red)[3]) {
+  const int t = threadIdx.x;
   const size_t HW = (size_t)g.Hf * g.Wf;
   const float* f = (dir ? flow_bwd : flow_fwd) + (size_t)n * 2 * HW;
   const float* o = (dir ? flow_fwd : flow_bwd) + (size_t)n * 2 * HW;
   uint8_t* mask = (dir ? mask_bwd : mask_fwd) + (size_t)n * HW;
-  const int tx0 = blockIdx.x * TX, ty0 = blockIdx.y * TY;
-  // second launch behind k_fbc_cert_dense: only the tiles it marked (every thread reads the same byte: block-uniform)
-  if (marked_only && mask[(size_t)ty0 * g.Wf + tx0] != TILE_MARK) return;
+  const int tx0 = bx * TX, ty0 = by * TY;
   const int wave = t >> 6, lane = t & 63;
   const int x = tx0 + lane;
   float2 fn[CH_PX];
@@ -937,6 +934,48 @@ k_fbc_pair(const float* __restrict__ flow_fwd, const float* __restrict__ flow_bw
     bad += __popcll(__ballot(!ok));
   }
   if (invalid && lane == 0 && bad) atomicAdd(&invalid[dir * N + n], bad);
+}
+
+__global__ void __launch_bounds__(NT)
+k_fbc_pair(const float* __restrict__ flow_fwd, const float* __restrict__ flow_bwd, uint8_t* __restrict__ mask_fwd,
+           uint8_t* __restrict__ mask_bwd, int32_t* __restrict__ invalid, int N, Up8Geom g) {
+  __shared__ float2 no[RH * RW];           // normalised opposite flow over the region
+  __shared__ float red[NWAVE][3];
+  fbc_pair_tile(flow_fwd, flow_bwd, mask_fwd, mask_bwd, invalid, N, g, blockIdx.x, blockIdx.y, blockIdx.z >> 1, blockIdx.z & 1, no, red);
+}
+
+// Second launch behind k_fbc_cert_dense: only the tiles it marked.  Few are: a small grid scans the list of
+// (direction, sample, tile) entries as k_prepare_staged does - block b owns entries b, b + G, ..., checks NT of them per
+// step (one mark byte per thread) and works through the marked ones.
+__global__ void __launch_bounds__(NT)
+k_fbc_pair_marked(const float* __restrict__ flow_fwd, const float* __restrict__ flow_bwd, uint8_t* __restrict__ mask_fwd,
+                  uint8_t* __restrict__ mask_bwd, int32_t* __restrict__ invalid, int N, Up8Geom g, int tiles_x, int tiles_y) {
+  __shared__ float2 no[RH * RW];
+  __shared__ float red[NWAVE][3];
+  __shared__ unsigned long long marks[NWAVE];
+  const int t = threadIdx.x, G = gridDim.x;
+  const size_t HW = (size_t)g.Hf * g.Wf;
+  const int per_n = tiles_x * tiles_y, nent = per_n * 2 * N;
+  for (int base = 0; blockIdx.x + (long)G * base < nent; base += NT) {
+    const long e = blockIdx.x + (long)G * (base + t);
+    bool marked = false;
+    if (e < nent) {
+      const int z = e / per_n, rem = e - z * per_n, by = rem / tiles_x, bx = rem - by * tiles_x;
+      const uint8_t* m = ((z & 1) ? mask_bwd : mask_fwd) + (size_t)(z >> 1) * HW;
+      marked = m[(size_t)(by * TY) * g.Wf + bx * TX] == TILE_MARK;
+    }
+    const unsigned long long mm = __ballot(marked);
+    if ((t & 63) == 0) marks[t >> 6] = mm;
+    __syncthreads();                                          // also orders these reads before any mask write below
+    for (int wv = 0; wv < NWAVE; ++wv)
+      for (unsigned long long todo = marks[wv]; todo; todo &= todo - 1) {
+        const int e2 = blockIdx.x + G * (base + 64 * wv + __builtin_ctzll(todo));
+        const int z = e2 / per_n, rem = e2 - z * per_n, by = rem / tiles_x, bx = rem - by * tiles_x;
+        fbc_pair_tile(flow_fwd, flow_bwd, mask_fwd, mask_bwd, invalid, N, g, bx, by, z >> 1, z & 1, no, red);
+        __syncthreads();                                      // the tile is done with `no` and `red`
+      }
+    __syncthreads();                                          // ... and everybody with `marks`
+  }
 }
 
 // ---- certified masks of DENSE composed flows (nframe > 2), both directions per block ------------------------------------
@@ -1304,8 +1343,14 @@ int run_flow_prepare(const float* lo_fwd, const float* lo_bwd, float* flow_fwd, 
                            bbox, mask_fwd, mask_bwd, invalid, N, g, force);
         CHECKED("k_fbc_cert_dense");
       }
-      hipLaunchKernelGGL(k_fbc_pair, dim3(grid.x, grid.y, 2 * N), dim3(NT), 0, st, flow_fwd, flow_bwd, mask_fwd,
-                         mask_bwd, invalid, N, g, cert ? 1 : 0);
+      if (cert) {
+        const long nent = (long)grid.x * grid.y * 2 * N;
+        hipLaunchKernelGGL(k_fbc_pair_marked, dim3((unsigned)(nent < 1024 ? nent : 1024)), dim3(NT), 0, st, flow_fwd, flow_bwd,
+                           mask_fwd, mask_bwd, invalid, N, g, (int)grid.x, (int)grid.y);
+      } else {
+        hipLaunchKernelGGL(k_fbc_pair, dim3(grid.x, grid.y, 2 * N), dim3(NT), 0, st, flow_fwd, flow_bwd, mask_fwd,
+                           mask_bwd, invalid, N, g);
+      }
       CHECKED("k_fbc_pair");
     }
     return PIXPRO_OK;
@@ -1323,7 +1368,7 @@ int run_flow_prepare(const float* lo_fwd, const float* lo_bwd, float* flow_fwd, 
   if (mask_fwd) {
     if (2 * N <= 65535 && grid.y <= 65535) {       // dense inputs: the tiled mask kernel does not up-sample anything
       hipLaunchKernelGGL(k_fbc_pair, dim3(grid.x, grid.y, 2 * N), dim3(NT), 0, st, flow_fwd, flow_bwd, mask_fwd,
-                         mask_bwd, invalid, N, make_geom(h, w, Hf, Wf, alpha1, a2), 0);
+                         mask_bwd, invalid, N, make_geom(h, w, Hf, Wf, alpha1, a2));
       CHECKED("k_fbc_pair");
     } else {
       hipLaunchKernelGGL(k_fbc, dim3(blocks_for(n)), dim3(TPB), 0, st, flow_fwd, flow_bwd, mask_fwd, (float*)nullptr,
