@@ -351,6 +351,7 @@ k_prepare_cert(const float* __restrict__ lo_fwd, const float* __restrict__ lo_bw
   __shared__ float4 tab[2][W0_H * W0_W];   // per own cell: normalised, inflated box {Lx, Ux, Ly, Uy} of the opposite flow
   __shared__ float part0[NWAVE_C][8];      // per-wave {min, max} x 4 channels of the cells under the tile
   __shared__ int odd_cells, wide_boxes;    // NaN / infinite cell seen (fminf would drop a NaN); boxes beyond the tolerance
+  __shared__ int uni[16];                  // wave 0's block-uniform results: certify, {ox, ex, oy, ey, shx, shy} x 2
   const int n = blockIdx.z, t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int tx0 = blockIdx.x * TX, ty0 = blockIdx.y * TYC;
@@ -390,31 +391,50 @@ k_prepare_cert(const float* __restrict__ lo_fwd, const float* __restrict__ lo_bw
   bool shifted = false;
   if (mask_fwd != nullptr) {                              // uniform: the barriers below are reached by every thread
     int ox[2] = {0, 0}, oy[2] = {0, 0}, ex[2] = {0, 0}, ey[2] = {0, 0};    // first / last cell offset per axis, per direction
-    certify = certify && odd_cells == 0;
+    // The block-uniform arithmetic (range of the own flows -> cell offsets -> window displacement) is done by wave 0 alone
+    // and handed over through LDS: five waves doing it redundantly was a third of the table cost.
+    if (wave == 0) {
+      certify = certify && odd_cells == 0;
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+        float lo[2], hi[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          float l = part0[0][4 * d + 2 * k], h = part0[0][4 * d + 2 * k + 1];
+#pragma unroll
+          for (int wv = 1; wv < NWAVE_C; ++wv) { l = fminf(l, part0[wv][4 * d + 2 * k]); h = fmaxf(h, part0[wv][4 * d + 2 * k + 1]); }
+          const float s = BOX_SLOP * fmaxf(fabsf(l), fabsf(h));
+          lo[k] = 8.f * (l - s); hi[k] = 8.f * (h + s);      // own flow of direction d in pixels
+          certify = certify && (hi[k] - lo[k] <= 64.f * MARG);                 // false for NaN too; bounds the casts below
+        }
+        if (certify) {
+          cell_offsets(lo[0], hi[0], g.sx, ox[d], ex[d]);
+          cell_offsets(lo[1], hi[1], g.sy, oy[d], ey[d]);
+          // The neighbourhood of every cell under the tile has to lie inside a 20 x 22 cell window.  Around the tile itself
+          // (the window that is already in LDS) that holds for own flows up to ~ +-24 px; a tile that moves further as a
+          // whole (fast ego-motion) gets a second window displaced by (shx, shy) cells, centred on where it lands.
+          const int span_x = MARG + (W0_W - ucols), span_y = MARG + (W0_H - urows);
+          certify = ex[d] - ox[d] <= MARG + span_x && ey[d] - oy[d] <= MARG + span_y;
+          shx[d] = min(max((ox[d] + ex[d]) / 2, ex[d] - span_x), ox[d] + MARG);
+          shy[d] = min(max((oy[d] + ey[d]) / 2, ey[d] - span_y), oy[d] + MARG);
+          if (ox[d] >= -MARG && ex[d] <= span_x && oy[d] >= -MARG && ey[d] <= span_y) shx[d] = shy[d] = 0;
+        }
+      }
+      if (lane == 0) {
+        uni[0] = certify ? 1 : 0;
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          uni[1 + 6 * d] = ox[d]; uni[2 + 6 * d] = ex[d]; uni[3 + 6 * d] = oy[d]; uni[4 + 6 * d] = ey[d];
+          uni[5 + 6 * d] = shx[d]; uni[6 + 6 * d] = shy[d];
+        }
+      }
+    }
+    __syncthreads();
+    certify = uni[0] != 0;
 #pragma unroll
     for (int d = 0; d < 2; ++d) {
-      float lo[2], hi[2];
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        float l = part0[0][4 * d + 2 * k], h = part0[0][4 * d + 2 * k + 1];
-#pragma unroll
-        for (int wv = 1; wv < NWAVE_C; ++wv) { l = fminf(l, part0[wv][4 * d + 2 * k]); h = fmaxf(h, part0[wv][4 * d + 2 * k + 1]); }
-        const float s = BOX_SLOP * fmaxf(fabsf(l), fabsf(h));
-        lo[k] = 8.f * (l - s); hi[k] = 8.f * (h + s);      // own flow of direction d in pixels
-        certify = certify && (hi[k] - lo[k] <= 64.f * MARG);                 // false for NaN too; bounds the casts below
-      }
-      if (certify) {
-        cell_offsets(lo[0], hi[0], g.sx, ox[d], ex[d]);
-        cell_offsets(lo[1], hi[1], g.sy, oy[d], ey[d]);
-        // The neighbourhood of every cell under the tile has to lie inside a 20 x 22 cell window.  Around the tile itself
-        // (the window that is already in LDS) that holds for own flows up to ~ +-24 px; a tile that moves further as a
-        // whole (fast ego-motion) gets a second window displaced by (shx, shy) cells, centred on where it lands.
-        const int span_x = MARG + (W0_W - ucols), span_y = MARG + (W0_H - urows);
-        certify = ex[d] - ox[d] <= MARG + span_x && ey[d] - oy[d] <= MARG + span_y;
-        shx[d] = min(max((ox[d] + ex[d]) / 2, ex[d] - span_x), ox[d] + MARG);
-        shy[d] = min(max((oy[d] + ey[d]) / 2, ey[d] - span_y), oy[d] + MARG);
-        if (ox[d] >= -MARG && ex[d] <= span_x && oy[d] >= -MARG && ey[d] <= span_y) shx[d] = shy[d] = 0;
-      }
+      ox[d] = uni[1 + 6 * d]; ex[d] = uni[2 + 6 * d]; oy[d] = uni[3 + 6 * d]; ey[d] = uni[4 + 6 * d];
+      shx[d] = uni[5 + 6 * d]; shy[d] = uni[6 + 6 * d];
     }
     certify = uniform(certify);
     shifted = uniform(certify && (shx[0] | shy[0] | shx[1] | shy[1]) != 0);
@@ -453,9 +473,10 @@ k_prepare_cert(const float* __restrict__ lo_fwd, const float* __restrict__ lo_bw
     }
     __syncthreads();
     if (certify) {                                        // column pass -> normalised boxes
-      for (int e = t; e < 2 * W0_H * W0_W; e += NT_C) {
-        const int d = e >= W0_H * W0_W, q = e - d * W0_H * W0_W, i = q / W0_W, j = q - i * W0_W;
-        if (i < urows && j < ucols) {
+      const int nd = urows * W0_W;                        // only the cell rows under the tile: one sweep of the block
+      for (int e = t; e < 2 * nd; e += NT_C) {
+        const int d = e >= nd, q = e - d * nd, i = q / W0_W, j = q - i * W0_W;
+        if (j < ucols) {
           float4 m = make_float4(INF, -INF, INF, -INF);
           for (int k = oy[d] - shy[d]; k <= ey[d] - shy[d]; ++k) {
             const float4 v = tmp[d][(MARG + i + k) * W0_W + j];
