@@ -50,13 +50,9 @@ struct Smem {
   float* AA;     // [LR][LS]   A = pow(clamp(S))
   float* Dm;     // [LR][LS]   dA/dS, later dS + dS^T
   float* DS;     // [LR][LS]   dS
-  float* rx;     // [64] reciprocal column norms of x, v, k, Y
+  float* rx;     // [64] reciprocal column norms of x and v (those of k and Y live in registers / wave-private slices)
   float* rv;
-  float* rk;
-  float* ry;
   float* nx2;    // [64] diag of the raw Gram matrix
-  float* tcol;   // [64]
-  float* scol;   // [64]
   float* part0;  // [NWAVES][64] x2: scratch of the column reductions, used alternately
   float* part1;
   float* qx;     // [64] each
@@ -71,7 +67,7 @@ struct Smem {
 __host__ __device__ inline int lr_rows(int P) { return (P + 3) / 4 * 4; }
 
 __host__ __device__ inline size_t smem_floats(int C, int P) {
-  return 2 * ((size_t)C * P + 4) + 3 * (size_t)lr_rows(P) * LS + 7 * 64 + 2 * NWAVES * 64 + 4 * 64 + 32 + 2 * 64 + 64;
+  return 2 * ((size_t)C * P + 4) + 3 * (size_t)lr_rows(P) * LS + 3 * 64 + 2 * NWAVES * 64 + 4 * 64 + 32 + 2 * 64 + 64;
 }
 
 __device__ __forceinline__ Smem carve(float* base, int C, int P) {
@@ -83,8 +79,8 @@ __device__ __forceinline__ Smem carve(float* base, int C, int P) {
   s.AA = p; p += LR * LS;
   s.Dm = p; p += LR * LS;
   s.DS = p; p += LR * LS;
-  s.rx = p; p += 64; s.rv = p; p += 64; s.rk = p; p += 64; s.ry = p; p += 64;
-  s.nx2 = p; p += 64; s.tcol = p; p += 64; s.scol = p; p += 64;
+  s.rx = p; p += 64; s.rv = p; p += 64;
+  s.nx2 = p; p += 64;
   s.part0 = p; p += NWAVES * 64; s.part1 = p; p += NWAVES * 64;
   s.qx = p; p += 64; s.qy = p; p += 64; s.kx = p; p += 64; s.ky = p; p += 64;
   s.misc = p; p += 32;
