@@ -224,3 +224,25 @@ def test_flow_prepare_without_workspace_equals_certified_route(dev):
     with pytest.raises(RuntimeError):
         nv.call("pixpro_flow_prepare_ws", nv.ptr(lo_f), nv.ptr(lo_b), nv.ptr(f2), nv.ptr(b2), nv.ptr(mf2), nv.ptr(mb2),
                 nv.ptr(cnt), N, F1, hw[0], hw[1], 1, 0.01, 0.5, nv.ptr(small), 64, nv.stream())
+
+
+@pytest.mark.parametrize("nfr,hw", [(2, (37, 53)), (3, (37, 53)), (2, (11, 29)), (4, (23, 9))])
+def test_flow_prepare_ragged_sizes_vs_oracle(dev, nfr, hw):
+    """Frame sizes that are no multiple of the 64 x 80 (64 x 40) tiles in either direction: partial tiles, partial
+    cell windows and the run / block certificates at the frame border, bit for bit against the oracle."""
+    from contrast import util
+    from oracle import pixpro_oracle as O
+    from recipes import smooth_flow
+    gen = torch.Generator().manual_seed(1000 + nfr + hw[0])
+    N, F1 = 3, nfr - 1
+    fw = smooth_flow((N, F1, 2, *hw), 0.6 / F1, gen)
+    fw[1] *= 4.0
+    bw = -fw.flip(1) + smooth_flow((N, F1, 2, *hw), 0.05 / F1, gen)
+    size = torch.tensor([8 * hw[0], 8 * hw[1]])
+    (f, _, mf), (b, _, mb) = util.apply_optical_flow(_data(fw, bw, size, nfr, dev), None, _args(True))
+    with O.aten_samplers():
+        (fo, _, mfo), (bo, _, mbo) = O.apply_optical_flow_file(fw, bw, size, True, 0.01, 0.5)
+    assert torch.equal(f.cpu(), fo) and torch.equal(b.cpu(), bo)
+    assert torch.equal(mf.cpu(), mfo) and torch.equal(mb.cpu(), mbo)
+    r = util.calc_mask_ratio(mf).cpu()
+    assert torch.allclose(r, (~mfo).float().mean((-1, -2)), atol=1e-6, rtol=0)
