@@ -1,15 +1,17 @@
-// Single-launch PPM -> flow-matched pixel loss -> backward for grids with P = H*W <= 64
+// Single-launch PPM -> flow-matched pixel loss -> backward for grids with P = H*W <= 64 and C * P <= 12,544
 // (7x7 at 224^2 crops, 2x2 at 64^2) and C in {128, 256}.
 //
 // One 512-thread work-group (8 wave64) per (loss direction, sample).  The sample's [C][P] fp32
-// tiles are contiguous in HBM (NCHW): each is one linear, fully coalesced 16 B/lane stream.
+// tiles are contiguous in HBM (NCHW: one linear 16 B/lane stream; channels_last: 4 pixels x 64 channels per
+// wave-load, transposed through LDS); waves 1..7 stream them, ONE tile request at a time (x -> v -> k -> x again),
+// wave 0 works out the sample points meanwhile (one round trip for all flow taps, consumed after the S contraction).
 // All six P x P / C x P contractions run on the exact-fp32 MFMA v_mfma_f32_16x16x4_f32 with both
 // operands read from LDS; S/A/dS never leave the CU.  The tiles stay RAW in LDS: the three L2
-// normalisations over C are applied as per-column reciprocal scales on the MFMA operands / in the
-// epilogues (n_x^2 is the diagonal of the raw Gram matrix), and the two projection dot products
-// are reduced on the accumulator registers (wave shuffles + one LDS hop across the 8 waves).
-// HBM latency is hidden inside the single resident work-group by register prefetch: k streams in
-// under the S contraction, the second read of x under the dA/dV contractions.
+// normalisations over C are applied as per-column reciprocal scales on the MFMA operands / folded into
+// the epilogues' per-column factors (n_x^2 is the diagonal of the raw Gram matrix), and the two projection dot
+// products are reduced on the accumulator registers (wave shuffles + one LDS hop across the 8 waves).
+// 7 x 7 specialisation (PC = 49): S as six mirrored upper tiles + row 48 on the vector ALU; the four C x P products on
+// three column tiles + column 48 as a dot product per row (edge_column).  DESIGN.md 4.1 has the measurements.
 //
 // Buffers over time (B0, B1 = two [C][P] LDS tiles):
 //   B0: x (S)  -> k (G) -> dY (dA, dV) -> x (dX, dx out)         B1: v (Y, dA, dV epilogue, dv out)
