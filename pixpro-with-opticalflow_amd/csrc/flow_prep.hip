@@ -1,4 +1,11 @@
-// Flow preparation kernels (HBM-bound, one thread per full-resolution pixel, coalesced along x).
+// Flow preparation kernels (HBM-bound; lane = output column, coalesced along x).
+//
+// Map of the file:  generic one-thread-per-pixel forms (k_upflow8, k_chain, k_fbc, k_prepare_single: stand-alone API,
+// flow_up = False, maps below ATen's small-output threshold)  ->  nframe = 2: k_prepare_cert (flows + masks settled by a
+// certificate: per-cell box table, whole runs of rows at once) and k_prepare_staged (marked tiles, taps from LDS)  ->
+// nframe > 2: k_chain_up8 (composed flows + bounding boxes of their 8 x 8 blocks), k_fbc_cert_dense (certificate from
+// those boxes, whole blocks from their own box), k_fbc_pair / k_fbc_pair_marked (taps from a mean-shifted LDS region)  ->
+// run_flow_prepare (routes, PIXPRO_FLOW_PATH).  DESIGN.md 4.3 / 4.4 has the reasoning and the measurements.
 //
 // Reference: contrast/util.py:174-248 (apply_optical_flow, file mode), :300-330 (concat_flow),
 // :252-297 (forward_backward_consistency), :333-366 (normalise helpers, calc_mask_ratio),
