@@ -145,9 +145,11 @@ __global__ void __launch_bounds__(TB) k_tl_prep(pixpro_problem pb, Dirs D, unsig
 
 // ---- k_tl_rnorms: grid (ceil(P/64), B, 3) -----------------------------------------------------------------------------
 __global__ void __launch_bounds__(TB) k_tl_rnorms(Dirs D, float* __restrict__ rx, float* __restrict__ rv,
-                                                  float* __restrict__ rk, int N, int C, int P, int normalize_k) {
+                                                  float* __restrict__ rk, float* __restrict__ cnt, int N, int C, int P,
+                                                  int normalize_k) {
   __shared__ float red[4][64];
   const int b = blockIdx.y, which = blockIdx.z, tx = threadIdx.x & 63, ty = threadIdx.x >> 6, j = blockIdx.x * 64 + tx;
+  if (blockIdx.x == 0 && which == 0 && threadIdx.x == 0) cnt[b] = 0.f;   // k_tl_prep (next launch) accumulates into it
   const pixpro_dir& dd = D.d[b / N];
   const float* s = (which == 0 ? dd.x : which == 1 ? dd.v : dd.k) + (size_t)(b % N) * C * P;
   float* o = (which == 0 ? rx : which == 1 ? rv : rk) + (size_t)b * P;
@@ -217,9 +219,42 @@ __device__ __forceinline__ void gram_tile(f32x4 (&acc)[2][2], const float* __res
 }
 
 // MODE 0: S -> A, D on the tiles ti <= tj, mirrored (grid: pairs, 1, B).  MODE 1: dSs on tile pairs (grid: pairs, 1, B).
+// loss_n[b] = sum of the strip partials / (cnt + 1e-6) (PixPro.py:241); loss = -2 sum_d mean_n loss_n (:247,431); one block
+__device__ __forceinline__ void tl_finish(const float* __restrict__ lpart, const float* __restrict__ cnt,
+                                          float* __restrict__ loss_n, float* __restrict__ loss, float* __restrict__ pos_num,
+                                          float* __restrict__ pos_mean, int B, int N, int strips, int P, float* red) {
+  float acc = 0.f;
+  for (int b = threadIdx.x; b < B; b += TB) {
+    float s = 0.f;
+    for (int k = 0; k < strips; ++k) s += lpart[(size_t)b * strips + k];
+    const float ln = s / (cnt[b] + 1e-6f);
+    loss_n[b] = ln;
+    pos_num[b] = cnt[b];
+    pos_mean[b] = cnt[b] / (float)P / (float)P;     // reference: mean(-1).mean(-1) in fp32 (< 1 ulp apart)
+    acc += ln;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float tsum = 0.f;
+    for (int k = 0; k < TB / 64; ++k) tsum += red[k];
+    *loss = -2.f * tsum / (float)N;
+  }
+  __syncthreads();
+}
+struct TlFin {                   // outputs of the loss reduction (MODE 1 of k_tl_gram does it in its first block)
+  float *loss_n, *loss, *pos_num, *pos_mean;
+  int B, strips;
+};
+
 template <int MODE>
-__global__ void __launch_bounds__(TB) k_tl_gram(Dirs D, TlWs w, int N, int C, int P, float p, float clampv) {
+__global__ void __launch_bounds__(TB) k_tl_gram(Dirs D, TlWs w, int N, int C, int P, float p, float clampv, TlFin fin) {
   __shared__ float As[16 * TSB], Bs[16 * TSB];
+  // The loss reduction needs every strip of the launch before (k_tl_strip<0>) and nothing of this one: when gradients
+  // are wanted it rides in the first block of this launch instead of a one-block launch of its own.
+  if (MODE == 1 && blockIdx.x == 0 && blockIdx.z == 0)
+    tl_finish(w.lpart, w.cnt, fin.loss_n, fin.loss, fin.pos_num, fin.pos_mean, fin.B, N, fin.strips, P, As);
   __shared__ float L1[MODE ? 64 * 65 : 1], L2[MODE ? 64 * 65 : 1];
   const int b = blockIdx.z, t = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, lr = lane & 15,
             lq = lane >> 4;
@@ -532,30 +567,13 @@ __global__ void __launch_bounds__(TB) k_tl_strip(pixpro_problem pb, Dirs D, TlWs
   }
 }
 
-// loss_n[b] = sum of the strip partials / (cnt + 1e-6) (PixPro.py:241); loss = -2 sum_d mean_n loss_n (:247,431)
+// forward-only launches: the same reduction as a launch of its own
 __global__ void __launch_bounds__(TB) k_tl_finish(const float* __restrict__ lpart, const float* __restrict__ cnt,
                                                   float* __restrict__ loss_n, float* __restrict__ loss,
                                                   float* __restrict__ pos_num, float* __restrict__ pos_mean, int B, int N,
                                                   int strips, int P) {
   __shared__ float red[TB / 64];
-  float acc = 0.f;
-  for (int b = threadIdx.x; b < B; b += TB) {
-    float s = 0.f;
-    for (int k = 0; k < strips; ++k) s += lpart[(size_t)b * strips + k];
-    const float ln = s / (cnt[b] + 1e-6f);
-    loss_n[b] = ln;
-    pos_num[b] = cnt[b];
-    pos_mean[b] = cnt[b] / (float)P / (float)P;     // reference: mean(-1).mean(-1) in fp32 (< 1 ulp apart)
-    acc += ln;
-  }
-  acc = wave_sum(acc);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    float tsum = 0.f;
-    for (int k = 0; k < TB / 64; ++k) tsum += red[k];
-    *loss = -2.f * tsum / (float)N;
-  }
+  tl_finish(lpart, cnt, loss_n, loss, pos_num, pos_mean, B, N, strips, P, red);
 }
 
 #define TL_CHECK(what)                        \
@@ -569,22 +587,21 @@ int run_tiled_c(const pixpro_problem& pb, const Dirs& D, const TlWs& w, float* l
   const int B = pb.N * pb.ndir, N = pb.N, C = pb.C, P = pb.H * pb.W, nt = (P + 63) / 64;
   const bool want_grad = D.d[0].dx != nullptr;
   const float g0 = pb.grad_scale * -2.f / (float)N;
-  if (hipMemsetAsync(w.cnt, 0, sizeof(float) * B, st) != hipSuccess) {
-    set_error("hipMemsetAsync failed");
-    return PIXPRO_ERR_LAUNCH;
-  }
+  const TlFin fin{loss_n, loss, pos_num, pos_mean, B, nt};
+  hipLaunchKernelGGL(k_tl_rnorms, dim3(nt, B, 3), dim3(TB), 0, st, D, w.rx, w.rv, w.rk, w.cnt, N, C, P, pb.normalize_k);
+  TL_CHECK("k_tl_rnorms");                 // also zeroes the counts k_tl_prep accumulates
   hipLaunchKernelGGL(k_tl_prep, dim3(B, PREP_S), dim3(TB), 0, st, pb, D, w.bits, w.cnt);
   TL_CHECK("k_tl_prep");
-  hipLaunchKernelGGL(k_tl_rnorms, dim3(nt, B, 3), dim3(TB), 0, st, D, w.rx, w.rv, w.rk, N, C, P, pb.normalize_k);
-  TL_CHECK("k_tl_rnorms");
-  hipLaunchKernelGGL(k_tl_gram<0>, dim3(nt * (nt + 1) / 2, 1, B), dim3(TB), 0, st, D, w, N, C, P, pb.p, pb.clamp);
+  hipLaunchKernelGGL(k_tl_gram<0>, dim3(nt * (nt + 1) / 2, 1, B), dim3(TB), 0, st, D, w, N, C, P, pb.p, pb.clamp, fin);
   TL_CHECK("k_tl_gram<0>");
   hipLaunchKernelGGL((k_tl_strip<MW, 0>), dim3(nt, B, 1), dim3(TB), 0, st, pb, D, w, g0, (int)want_grad);
   TL_CHECK("k_tl_strip<0>");
-  hipLaunchKernelGGL(k_tl_finish, dim3(1), dim3(TB), 0, st, w.lpart, w.cnt, loss_n, loss, pos_num, pos_mean, B, N, nt, P);
-  TL_CHECK("k_tl_finish");
-  if (!want_grad) return PIXPRO_OK;
-  hipLaunchKernelGGL(k_tl_gram<1>, dim3(nt * (nt + 1) / 2, 1, B), dim3(TB), 0, st, D, w, N, C, P, pb.p, pb.clamp);
+  if (!want_grad) {
+    hipLaunchKernelGGL(k_tl_finish, dim3(1), dim3(TB), 0, st, w.lpart, w.cnt, loss_n, loss, pos_num, pos_mean, B, N, nt, P);
+    TL_CHECK("k_tl_finish");
+    return PIXPRO_OK;
+  }
+  hipLaunchKernelGGL(k_tl_gram<1>, dim3(nt * (nt + 1) / 2, 1, B), dim3(TB), 0, st, D, w, N, C, P, pb.p, pb.clamp, fin);
   TL_CHECK("k_tl_gram<1>");
   hipLaunchKernelGGL((k_tl_strip<MW, 1>), dim3(nt, B, 2), dim3(TB), 0, st, pb, D, w, g0, 1);
   TL_CHECK("k_tl_strip<1>");
