@@ -149,7 +149,7 @@ int pixpro_ppm_loss(const pixpro_problem* pb, const pixpro_dir* dirs, float* los
     return run_finalize(loss_n, loss, pb->N * pb->ndir, pb->N, (hipStream_t)stream);
   }
   if (!workspace) return bad("this shape takes a multi-launch path and needs a workspace");
-  // grids beyond 64 positions (14 x 14 at 448^2 crops): the tiled MFMA path, 7 launches; anything else: the staged path
+  // grids beyond 64 positions (14 x 14 at 448^2 crops): the tiled MFMA path, 6 launches; anything else: the staged path
   if (tiled_supported(*pb) && aligned && !getenv("PIXPRO_NO_TILED"))
     return run_tiled(*pb, dirs, loss_n, pos_num, pos_mean, loss, workspace, workspace_bytes, (hipStream_t)stream);
   return run_generic(*pb, dirs, loss_n, pos_num, pos_mean, loss, workspace, workspace_bytes, (hipStream_t)stream, 0);
