@@ -185,13 +185,6 @@ __device__ __forceinline__ void store_tile(float* __restrict__ dst, const float*
     *reinterpret_cast<float4*>(dst + e) = *reinterpret_cast<const float4*>(src + e);
 }
 
-// Which channel is row rho (0..15) of the T-th 16-row MFMA tile of a C x P product.  Not 16 T + rho: the accumulator
-// layout gives lane group lq the tile rows 4 lq .. 4 lq + 3, and with consecutive channels the four groups of an
-// epilogue access land 4 banks apart (row stride 49 floats: 4-way conflicts on every read of v / x and write of dY / dv
-// / dx at the accumulator positions).  Here the four 4-row groups of a tile are 16 channels apart (49 * 16 = 16 mod 64:
-// bank windows 16 apart, conflict-free) and four such tiles interleave inside a block of 64 channels.
-__device__ __forceinline__ int tile_row(int T, int rho) { return 64 * (T >> 2) + 4 * (T & 3) + 16 * (rho >> 2) + (rho & 3); }
-
 // rn[j] = 1 / max(||buf[:,j]||, 1e-12) for j < P  (ends with a barrier)
 __device__ __forceinline__ void col_rnorms(const float* buf, float* rn, float* part, int C, int P) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -276,7 +269,7 @@ template <int MT>
 __device__ __forceinline__ float edge_column(const float* __restrict__ tile, int P, float wl, float* __restrict__ ws) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int rl = lane & 31, hi = lane >> 5;
-  const int row = tile_row(wave + NWAVES * min(rl >> 4, MT - 1), rl & 15);
+  const int row = 16 * (wave + NWAVES * min(rl >> 4, MT - 1)) + (rl & 15);
   ws[lane] = wl;                            // lanes >= 49 pass 0
   const float* a = tile + row * P + 25 * hi;
   const float* w = ws + 25 * hi;
@@ -299,7 +292,7 @@ __device__ __forceinline__ float edge_column_bits(const float* __restrict__ tile
                                                   const float* __restrict__ rk) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int rl = lane & 31;
-  const int row = tile_row(wave + NWAVES * min(rl >> 4, MT - 1), rl & 15);
+  const int row = 16 * (wave + NWAVES * min(rl >> 4, MT - 1)) + (rl & 15);
   const float* a = tile + row * P;
   unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)bits), hi = __builtin_amdgcn_readfirstlane((unsigned)(bits >> 32));
   float e0 = 0.f, e1 = 0.f;
@@ -510,8 +503,8 @@ ppm_fused_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* _
   const bool want_grad = dd.dx != nullptr;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   // row of the wave's m-th C-tile owned by this lane as A operand / as accumulator register r
-  auto arow = [&](int m) { return tile_row(wave + NWAVES * m, lr); };
-  auto crow = [&](int m, int r) { return tile_row(wave + NWAVES * m, 4 * lq + r); };
+  auto arow = [&](int m) { return 16 * (wave + NWAVES * m) + lr; };
+  auto crow = [&](int m, int r) { return 16 * (wave + NWAVES * m) + 4 * lq + r; };
 
   STAMP(0);
   // ---- waves 1..7: x -> B0 and v -> B1 in flight together; wave 0: bin centres, flow taps, threshold ----
@@ -750,7 +743,7 @@ ppm_fused_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* _
   constexpr bool EDGE = PC == 49;
   constexpr int NTM = EDGE ? 3 : NT;
   const bool elive = lane < 16 * MT;                      // lanes that own an edge value
-  const int erow = tile_row(wave + NWAVES * min((lane & 31) >> 4, MT - 1), lane & 15);   // ... and its row
+  const int erow = 16 * (wave + NWAVES * min((lane & 31) >> 4, MT - 1)) + (lane & 15);   // ... and its row
   f32x4 Y[MT][NTM];
 #pragma unroll
   for (int m = 0; m < MT; ++m)
