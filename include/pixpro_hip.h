@@ -178,7 +178,9 @@ int pixpro_mask_ratio(const uint8_t* mask, float* ratio, int32_t N, int64_t pixe
 /* ---- multi-tensor updates around the path ("next" rows of SURVEY.md §8f) ------------- */
 /* Momentum (EMA) update, PixPro.py:321-337: pk = pk*m + pq*(1-m) for `count` tensors.
  * pq_ptrs / pk_ptrs / sizes: DEVICE arrays of count pointers / element counts; m is the
- * python double of PixPro.py:326 (the kernel uses fl32(m) and fl32(1-m) like the reference). */
+ * python double of PixPro.py:326 (the kernel uses fl32(m) and fl32(1-m) like the reference).
+ * count <= 2048 per call (PIXPRO_ERR_ARG beyond: split the list); tensors need not be 16-B aligned (a scalar path takes
+ * those that are not).  The same limits hold for pixpro_lars_sgd_step. */
 int pixpro_ema_update(const float* const* pq_ptrs, float* const* pk_ptrs,
                       const int64_t* sizes, int32_t count, double m, void* stream);
 /* LARS + SGD-momentum step without host syncs (contrast/lars.py:109-151 followed by
