@@ -7,6 +7,8 @@ import torch
 
 from . import _native as nv
 
+MAX_TENSORS = 2048     # per C call (include/pixpro_hip.h)
+
 
 class _Table:
     """Device arrays of pointers / sizes for a list of tensors; rebuilt only when a pointer moves."""
@@ -56,7 +58,10 @@ def ema_update(params_q, params_k, m):
     _check(pq + pk, "ema_update")
     _same_layout([pq, pk], "ema_update")
     tab = _ema_table.get([pq, pk], pq[0].device)
-    nv.call("pixpro_ema_update", nv.ptr(tab[0]), nv.ptr(tab[1]), nv.ptr(tab[2]), len(pq), float(m), nv.stream())
+    for a in range(0, len(pq), MAX_TENSORS):        # the kernel's chunk table holds MAX_TENSORS entries per call
+        b = min(a + MAX_TENSORS, len(pq))
+        nv.call("pixpro_ema_update", nv.ptr(tab[0][a:b]), nv.ptr(tab[1][a:b]), nv.ptr(tab[2][a:b]), b - a, float(m),
+                nv.stream())
 
 
 class LarsSgdStep:
@@ -84,7 +89,10 @@ class LarsSgdStep:
             grads.append(p.grad if p.grad.stride() == p.stride() else p.grad.contiguous(
                 memory_format=torch.channels_last if p.dim() == 4 and not p.is_contiguous() else torch.contiguous_format))
         tab = self.table.get([[p.data for p in self.params], grads, self.bufs], self.params[0].device)
-        nv.call("pixpro_lars_sgd_step", nv.ptr(tab[0]), nv.ptr(tab[1]), nv.ptr(tab[2]), nv.ptr(tab[3]),
-                nv.ptr(self.wd), nv.ptr(self.adapt), len(self.params), float(lr), float(self.momentum),
-                float(self.trust), float(self.eps), int(self.first), nv.ptr(self.norms2), nv.stream())
+        for a in range(0, len(self.params), MAX_TENSORS):
+            b = min(a + MAX_TENSORS, len(self.params))
+            nv.call("pixpro_lars_sgd_step", nv.ptr(tab[0][a:b]), nv.ptr(tab[1][a:b]), nv.ptr(tab[2][a:b]),
+                    nv.ptr(tab[3][a:b]), nv.ptr(self.wd[a:b]), nv.ptr(self.adapt[a:b]), b - a, float(lr),
+                    float(self.momentum), float(self.trust), float(self.eps), int(self.first),
+                    nv.ptr(self.norms2[2 * a:2 * b]), nv.stream())
         self.first = False

@@ -95,6 +95,13 @@ def test_multi_tensor_chunk_walk_edge_sizes(dev):
     ema_update(dq, dk, m)
     for i, (a, b) in enumerate(zip(dk, want)):
         assert torch.equal(a.cpu(), b), (i, a.numel())
+    # more tensors than one C call takes (2048): the wrapper splits the list
+    many_q = [torch.randn(3 + i % 3, generator=gen) for i in range(2100)]
+    many_k = [torch.randn(3 + i % 3, generator=gen) for i in range(2100)]
+    dmq, dmk = [t.to(dev) for t in many_q], [t.to(dev) for t in many_k]
+    ema_update(dmq, dmk, m)
+    for a, b in zip(dmk, O.momentum_update(many_q, many_k, m)):
+        assert torch.equal(a.cpu(), b)
     # LARS: every third tensor 1-D-style (no decay, no adaptation)
     ps = [torch.nn.Parameter(t.to(dev).clone()) for t in pq]
     wds = [0.0 if i % 3 == 0 else 1e-4 for i in range(len(ps))]
