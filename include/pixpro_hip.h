@@ -84,7 +84,7 @@ typedef struct pixpro_dir {
   float* dv;
 } pixpro_dir;
 
-int pixpro_version(void);
+int pixpro_version(void);            /* 100 * major + minor: 110 = round 2 (flow_prepare_ws added; nothing removed) */
 const char* pixpro_last_error(void);
 
 /* ---- K1+K2+K3+K4 fused: PixPro.featprop (PixPro.py:339-363) + F.normalize (:380) +

@@ -109,7 +109,7 @@ using namespace pixpro;
 
 extern "C" {
 
-int pixpro_version(void) { return 100; }
+int pixpro_version(void) { return 110; }   // 1.1: pixpro_flow_prepare_ws, pixpro_flow_prepare_workspace_bytes
 
 const char* pixpro_last_error(void) { return g_err; }
 
