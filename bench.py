@@ -308,13 +308,10 @@ def _free_port():
 def launch_ranks(a):
     """`python bench.py --gpus N` with no torch.distributed.run around it: start one child process per GPU (the reference's
     launch is one MPI rank per GPU, main_pretrain_mpirun.py:17-49) with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the
-    environment, pass rank 0's JSON line through and exit non-zero when any rank fails.  This parent never touches the GPU
-    (torch.cuda.device_count() does not initialise it), so nothing that has initialised HIP is ever replaced or forked."""
+    environment, pass rank 0's JSON line through and exit non-zero when any rank fails.  This parent makes no GPU query at
+    all (not even a device count: without amdsmi torch counts devices through hipGetDeviceCount, which initialises HIP);
+    every rank checks for itself that it has a device of its own and fails the launch otherwise."""
     import subprocess
-    rehearsal = os.environ.get("PIXPRO_REHEARSAL") == "1"
-    have = torch.cuda.device_count()
-    if have < a.gpus and not rehearsal and not a.dry_launch:
-        sys.exit(f"[bench] --gpus {a.gpus} but only {have} GPU(s) are visible (PIXPRO_REHEARSAL=1 shares one GPU over gloo)")
     port = _free_port()
     procs = []
     for r in range(a.gpus):

@@ -245,6 +245,7 @@ int pixpro_flow_prepare_ws(const float* lo_fwd, const float* lo_bwd, float* flow
   if (N < 1 || F1 < 1 || h < 2 || w < 2) return bad("N, F1 >= 1 and h, w >= 2 required");
   if (workspace && workspace_bytes < flow_prepare_workspace_bytes(N, F1, h, w, flow_up))
     return bad("workspace smaller than pixpro_flow_prepare_workspace_bytes");
+  if (workspace && ((uintptr_t)workspace & 15) != 0) return bad("workspace must be 16-byte aligned");
   return run_flow_prepare(lo_fwd, lo_bwd, flow_fwd, flow_bwd, mask_fwd, mask_bwd, invalid_count, N, F1, h, w,
                           flow_up, alpha1, alpha2, workspace, workspace_bytes, (hipStream_t)stream);
 }

@@ -51,9 +51,10 @@ __device__ __forceinline__ ChunkWalk chunk_table(const int64_t* __restrict__ siz
 #pragma unroll
   for (int e = 0; e < PER; ++e) {
     const int t = tid * PER + e;
-    if (t <= count) starts[t] = run;       // starts[count] = total
+    if (t <= count) starts[t] = run;       // starts[count] = total, for count < MAXT
     run += c[e];
   }
+  if (tid == TPB - 1 && count == MAXT) starts[MAXT] = run;   // a full table: no thread's entries reach t == count
   __syncthreads();
   const int total = starts[count];
   ChunkWalk w;

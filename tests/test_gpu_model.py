@@ -120,6 +120,41 @@ def test_multi_tensor_chunk_walk_edge_sizes(dev):
             assert torch.allclose(p_.detach().cpu(), ref_p[i], rtol=3e-6, atol=1e-7), (it, i, sizes[i])
 
 
+@pytest.mark.parametrize("count", [2047, 2048, 2049, 4096, 4100])
+def test_multi_tensor_full_table(dev, count):
+    """Lists around the 2048-entry chunk table of one C call: a full table (its total is written by the last thread, not
+    by an entry of its own) and the wrapper's split just beyond it - EMA bit for bit, LARS + SGD with adaptive tensors on
+    both sides of every split, two steps (first_step is shared by the sub-calls of a step)."""
+    from contrast.multi_tensor import ema_update, LarsSgdStep
+    from oracle import pixpro_oracle as O
+    gen = torch.Generator().manual_seed(count)
+    sizes = [2 + (i * 7) % 11 for i in range(count)]
+    for i in (0, 2046, 2047, 2048, count - 1):           # a few tensors of more than one chunk next to the boundaries
+        if i < count:
+            sizes[i] = 16384 + 5 + i % 3
+    pq = [torch.randn(n, generator=gen) for n in sizes]
+    pk = [torch.randn(n, generator=gen) for n in sizes]
+    m = O.momentum_coefficient(0.99, 5, 8750)
+    dq, dk = [t.to(dev) for t in pq], [t.to(dev) for t in pk]
+    ema_update(dq, dk, m)
+    for i, (a, b) in enumerate(zip(dk, O.momentum_update(pq, pk, m))):
+        assert torch.equal(a.cpu(), b), i
+    ps = [torch.nn.Parameter(t.to(dev).clone()) for t in pq]
+    wds = [0.0 if i % 5 == 0 else 1e-4 for i in range(count)]
+    ads = [i % 5 != 0 for i in range(count)]
+    step = LarsSgdStep(ps, wds, ads, momentum=0.9)
+    ref_p, ref_b = [t.clone() for t in pq], [None] * count
+    for it in range(2):
+        gs = [torch.randn(n, generator=gen) for n in sizes]
+        for p_, g_ in zip(ps, gs):
+            p_.grad = g_.to(dev)
+        step.step(0.3)
+        for i in range(count):
+            ref_p[i], ref_b[i] = O.lars_sgd_step(ref_p[i], gs[i], ref_b[i], 0.3, 0.9, wds[i], ads[i])
+        for i, p_ in enumerate(ps):
+            assert torch.allclose(p_.detach().cpu(), ref_p[i], rtol=3e-6, atol=1e-7), (it, i, sizes[i])
+
+
 def test_lars_golden_trajectory(dev):
     from contrast.lars import LARS, add_weight_decay
     g = load_golden("lars")
