@@ -20,15 +20,20 @@
 namespace pixpro {
 namespace {
 
+#ifndef TL_ABL
+#define TL_ABL 0                 // timing ablations (tools/tl_abl.sh): 1 strip<1> epilogue traffic off, 2 no MFMA, 4 no copies
+#endif
 constexpr int TB = 256;          // threads per work-group: 4 waves
 constexpr int TSB = 80;          // LDS row stride of a 64-wide operand slab (conflict-free MFMA operand reads)
 
 struct TlWs {                    // workspace carve (floats unless noted)
   float *rx, *rv, *rk;           // [B][P] reciprocal column norms
   float *cnt, *lpart;            // [B], [B][strips]
-  float *A, *Dm, *dSs, *Av;      // [B][P][P]; Av[s][i] = rv[s] A[s][i], dSs rows pre-scaled by rx
+  float *A, *Dm, *dSs, *Av;      // [B][P][P]; Av[n][k] = rv[k] A[n][k], dSs[n][k] = rx[k] (dS + dS^T)[n][k]: the scales of
+                                 // the strip products sit on the COLUMNS, row n of the stored matrix is operand column n
   float *dY;                     // [B][C][P]
   unsigned long long* bits;      // [B][P][W64]
+  float* zero;                   // 16 floats of zeros (written by k_tl_rnorms): what the copies fetch for k beyond P
 };
 
 inline size_t al256(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
@@ -37,7 +42,7 @@ size_t tl_bytes(const pixpro_problem& pb) {
   const size_t B = (size_t)pb.N * pb.ndir, P = (size_t)pb.H * pb.W, R = (size_t)pb.C * P, Q = P * P, W64 = (P + 63) / 64;
   const size_t strips = (P + 63) / 64;
   return 3 * al256(B * P * 4) + al256(B * 4) + al256(B * strips * 4) + 4 * al256(B * Q * 4) + al256(B * R * 4) +
-         al256(B * P * W64 * 8) + 4096;
+         al256(B * P * W64 * 8) + 256 + 4096;
 }
 
 TlWs tl_carve(void* ws, const pixpro_problem& pb) {
@@ -52,6 +57,7 @@ TlWs tl_carve(void* ws, const pixpro_problem& pb) {
   w.Av = (float*)take(B * Q * 4);
   w.dY = (float*)take(B * R * 4);
   w.bits = (unsigned long long*)take(B * P * W64 * 8);
+  w.zero = (float*)take(64);
   return w;
 }
 
@@ -145,11 +151,12 @@ __global__ void __launch_bounds__(TB) k_tl_prep(pixpro_problem pb, Dirs D, unsig
 
 // ---- k_tl_rnorms: grid (ceil(P/64), B, 3) -----------------------------------------------------------------------------
 __global__ void __launch_bounds__(TB) k_tl_rnorms(Dirs D, float* __restrict__ rx, float* __restrict__ rv,
-                                                  float* __restrict__ rk, float* __restrict__ cnt, int N, int C, int P,
-                                                  int normalize_k) {
+                                                  float* __restrict__ rk, float* __restrict__ cnt, float* __restrict__ zero,
+                                                  int N, int C, int P, int normalize_k) {
   __shared__ float red[4][64];
   const int b = blockIdx.y, which = blockIdx.z, tx = threadIdx.x & 63, ty = threadIdx.x >> 6, j = blockIdx.x * 64 + tx;
   if (blockIdx.x == 0 && which == 0 && threadIdx.x == 0) cnt[b] = 0.f;   // k_tl_prep (next launch) accumulates into it
+  if (blockIdx.x == 0 && blockIdx.y == 0 && which == 0 && threadIdx.x < 16) zero[threadIdx.x] = 0.f;
   const pixpro_dir& dd = D.d[b / N];
   const float* s = (which == 0 ? dd.x : which == 1 ? dd.v : dd.k) + (size_t)(b % N) * C * P;
   float* o = (which == 0 ? rx : which == 1 ? rv : rk) + (size_t)b * P;
@@ -170,52 +177,146 @@ __global__ void __launch_bounds__(TB) k_tl_rnorms(Dirs D, float* __restrict__ rx
   if (ty == 0 && j < P) o[j] = 1.f / fmaxf(sqrtf(red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx]), 1e-12f);
 }
 
+// ---- XCD-aware placement ----------------------------------------------------------------------------------------------
+// Consecutive work-groups of a launch go to the eight XCDs in turn, each with its own 4 MB L2.  The `per` work-groups that
+// share one (direction, sample) - the ten tile pairs of a Gram product, the strips of a strip product - get linear ids 8
+// apart: they run on ONE XCD at about the same time, the tiles they share are fetched into that L2 once, and what one
+// launch writes for a sample (A, Av, dY, dSs) is still in the L2 of the XCD that reads it in the next launch.
+// (Placement only changes speed; nothing depends on it.)  Launches are 1-D: B * per work-groups.
+__device__ __forceinline__ void xcd_item(int per, int B, int& b, int& item) {
+  const int L = blockIdx.x, full = (B / 8) * 8 * per;
+  if (L < full) {
+    const int slot = L >> 3;
+    b = 8 * (slot / per) + (L & 7);
+    item = slot % per;
+  } else {
+    const int r = L - full;
+    b = (B / 8) * 8 + r / per;
+    item = r % per;
+  }
+}
+
+// ---- asynchronous global -> LDS copies (global_load_lds_dwordx4) ------------------------------------------------------
+// One wave instruction moves 64 x 16 B: every lane names its own SOURCE address, the destination is the wave-uniform LDS
+// base + 16 * lane.  A slab image is therefore linear in LDS and any swizzle is applied to the source side and to the
+// reads (the same involution on both).  The copies are counted in vmcnt; nothing orders them against LDS reads except the
+// issuing wave's s_waitcnt vmcnt(n) followed by a barrier, so the loops below use raw s_barrier (a __syncthreads() would
+// drain every copy in flight with vmcnt(0)).
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+__device__ __forceinline__ void dma16(const float* src, float* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)lds_wave_base, 16, 0, 0);
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void lds_barrier() {          // LDS traffic of this wave retired, then the work-group barrier
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
 // ---- P x P products over K = C on 64 x 64 tiles --------------------------------------------------------------------------
-// One 64 x 64 x C product: acc[i][j] += sum_c L[c*P + m0 + ..] * Rm[c*P + n0 + ..]; wave w owns the 32 x 32 block
-// (w >> 1, w & 1).  Columns beyond P read as zero.
-__device__ __forceinline__ void gram_tile(f32x4 (&acc)[2][2], const float* __restrict__ L, const float* __restrict__ Rm,
-                                          int m0, int n0, int C, int P, float* As, float* Bs) {
+// NP 64 x 64 x C products at once: acc[q][i][j] += sum_c L_q[c*P + m0_q + ..] * R_q[c*P + n0_q + ..]; wave w owns the
+// 32 x 32 block (w >> 1, w & 1) of every product.  Round 3: the slabs arrive by LDS-DMA, two slabs ahead of the MFMAs in a
+// ring of three buffers, one barrier per slab (round 2: 16-deep slabs through registers, two barriers each - the kernel
+// waited for memory latency 16 times per tile with 16 MFMAs per wave in between).  One product runs on 32-deep slabs, the
+// pair of the backward pass on 16-deep ones: four copies per wave and slab and 48 KB of LDS either way.
+// Slab image [k][64], the 16-B chunks of odd k rows swapped in pairs 16 floats apart (column ^ 16): the MFMA operand reads
+// (lanes 0-31 of a ds_read_b32 = two k rows x 16 columns) are conflict-free.  Columns beyond P fetch the row's last valid
+// chunk instead (finite duplicates; their products land in rows / columns nobody stores).
+constexpr int GNB = 3;                          // ring length
+constexpr int GRING = GNB * 2 * 32 * 64;        // floats: 48 KB
+constexpr int EPS = 68;                         // row stride of the epilogue tiles (16-B aligned rows, conflict-free writes)
+struct GramOp {
+  const float* L;
+  const float* Rm;
+  int m0, n0;
+};
+template <int NP>
+__device__ __forceinline__ void gram_core(f32x4 (&acc)[NP][2][2], const GramOp (&op)[NP], int C, int P, float* ring) {
+  constexpr int GKT = 32 / NP, SLAB = GKT * 64, PIECES = GKT / 16;      // k rows per slab; copies per wave and operand
   const int t = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, lr = lane & 15, lq = lane >> 4;
   const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
-  const int col = t & 63, k4 = t >> 6;                 // loader: 4 k rows per thread, 64 consecutive columns per wave
-  const bool mok = m0 + col < P, nok = n0 + col < P;
   // 16 x 16 sub-tiles wholly beyond P (P = 196 = 12.25 sub-tiles per side) issue no MFMA (wave-uniform)
-  bool live[2][2];
+  bool live[NP][2][2], full = true, any = false;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int q = 0; q < NP; ++q)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) live[i][j] = (m0 + wm + 16 * i < P) && (n0 + wn + 16 * j < P);
-  float ra[4], rb[4];
-  auto request = [&](int k0) {
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const size_t o = (size_t)(k0 + k4 + 4 * e) * P;
-      ra[e] = mok ? L[o + m0 + col] : 0.f;
-      rb[e] = nok ? Rm[o + n0 + col] : 0.f;
-    }
-  };
-  request(0);
-  for (int k0 = 0; k0 < C; k0 += 16) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { As[(k4 + 4 * e) * TSB + col] = ra[e]; Bs[(k4 + 4 * e) * TSB + col] = rb[e]; }
-    __syncthreads();
-    if (k0 + 16 < C) request(k0 + 16);
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      float av[2], bv[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        av[i] = As[(4 * ks + lq) * TSB + wm + 16 * i + lr];
-        bv[i] = Bs[(4 * ks + lq) * TSB + wn + 16 * i + lr];
+      for (int j = 0; j < 2; ++j) {
+        live[q][i][j] = (op[q].m0 + wm + 16 * i < P) && (op[q].n0 + wn + 16 * j < P);
+        full = full && live[q][i][j];
+        any = any || live[q][i][j];
       }
+  // this wave's pieces of a slab: k rows 4 PIECES wave .. + 4 PIECES - 1 of every operand
+  const float* srcL[NP][PIECES];
+  const float* srcR[NP][PIECES];
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+  for (int q = 0; q < NP; ++q)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-          if (live[i][j]) acc[i][j] = mfma16(av[i], bv[j], acc[i][j]);
+    for (int e = 0; e < PIECES; ++e) {
+      const int kk = 4 * PIECES * wave + 4 * e + lq, ch = lr ^ ((kk & 1) << 2);
+      srcL[q][e] = op[q].L + (size_t)kk * P + min(op[q].m0 + 4 * ch, P - 4);
+      srcR[q][e] = op[q].Rm + (size_t)kk * P + min(op[q].n0 + 4 * ch, P - 4);
     }
-    __syncthreads();
+  const size_t slab_step = (size_t)GKT * P;
+  auto issue = [&](int s) {
+    float* buf = ring + (s % GNB) * NP * 2 * SLAB + 256 * PIECES * wave;
+#pragma unroll
+    for (int q = 0; q < NP; ++q)
+#pragma unroll
+      for (int e = 0; e < PIECES; ++e) {
+        dma16(srcL[q][e] + s * slab_step, buf + (2 * q) * SLAB + 256 * e);
+        dma16(srcR[q][e] + s * slab_step, buf + (2 * q + 1) * SLAB + 256 * e);
+      }
+  };
+  constexpr int PER = NP * 2 * PIECES;          // copies per wave and slab (4)
+  const int S = C / GKT;
+  issue(0);
+  if (S > 1) issue(1);
+  const int sw = 16 * (lq & 1);
+  for (int s = 0; s < S; ++s) {
+    if (s + 1 < S) wait_vm<PER>(); else wait_vm<0>();   // this wave's pieces of slab s have landed
+    lds_barrier();                                      // ... everybody's; and everybody is done reading slab s - 1
+    if (s + 2 < S) issue(s + 2);                        // into the buffer slab s - 1 occupied
+    const float* buf = ring + (s % GNB) * NP * 2 * SLAB;
+    if (full) {                                         // the common case: straight-line code
+#pragma unroll
+      for (int ks = 0; ks < GKT / 4; ++ks)
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+          float av[2], bv[2];
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            av[i] = buf[(2 * q) * SLAB + (4 * ks + lq) * 64 + ((wm + 16 * i + lr) ^ sw)];
+            bv[i] = buf[(2 * q + 1) * SLAB + (4 * ks + lq) * 64 + ((wn + 16 * i + lr) ^ sw)];
+          }
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[q][i][j] = mfma16(av[i], bv[j], acc[q][i][j]);
+        }
+    } else if (any) {
+#pragma unroll
+      for (int ks = 0; ks < GKT / 4; ++ks)
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+          float av[2], bv[2];
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            av[i] = buf[(2 * q) * SLAB + (4 * ks + lq) * 64 + ((wm + 16 * i + lr) ^ sw)];
+            bv[i] = buf[(2 * q + 1) * SLAB + (4 * ks + lq) * 64 + ((wn + 16 * i + lr) ^ sw)];
+          }
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              if (live[q][i][j]) acc[q][i][j] = mfma16(av[i], bv[j], acc[q][i][j]);
+        }
+    }
   }
+  lds_barrier();                                        // the ring may be reused (epilogue tiles)
 }
 
 // MODE 0: S -> A, D on the tiles ti <= tj, mirrored (grid: pairs, 1, B).  MODE 1: dSs on tile pairs (grid: pairs, 1, B).
@@ -248,73 +349,117 @@ struct TlFin {                   // outputs of the loss reduction (MODE 1 of k_t
   int B, strips;
 };
 
+// Row-major store of a 64 x 64 tile staged in LDS ([64][EPS]): wave w takes rows 16 w .. + 15, 16 lanes per row (256 B
+// contiguous, 16 B per lane); rows / 4-column groups beyond P are skipped (P % 4 == 0).
+__device__ __forceinline__ void tile_rows_out(const float* tile, float* __restrict__ dst, int r0, int c0, int P) {
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, c4 = lane & 15;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = 16 * wave + 4 * i + (lane >> 4);
+    if (r0 + row < P && c0 + 4 * c4 < P)
+      *reinterpret_cast<float4*>(dst + (size_t)(r0 + row) * P + c0 + 4 * c4) =
+          *reinterpret_cast<const float4*>(tile + row * EPS + 4 * c4);
+  }
+}
+
 template <int MODE>
 __global__ void __launch_bounds__(TB) k_tl_gram(Dirs D, TlWs w, int N, int C, int P, float p, float clampv, TlFin fin) {
-  __shared__ float As[16 * TSB], Bs[16 * TSB];
+  __shared__ __attribute__((aligned(16))) float ring[GRING];      // 48 KB: slab ring, then the epilogue tiles
+  static_assert(GRING >= 2 * 64 * EPS, "two epilogue tiles fit in the slab ring");
   // The loss reduction needs every strip of the launch before (k_tl_strip<0>) and nothing of this one: when gradients
   // are wanted it rides in the first block of this launch instead of a one-block launch of its own.
-  if (MODE == 1 && blockIdx.x == 0 && blockIdx.z == 0)
-    tl_finish(w.lpart, w.cnt, fin.loss_n, fin.loss, fin.pos_num, fin.pos_mean, fin.B, N, fin.strips, P, As);
-  __shared__ float L1[MODE ? 64 * 65 : 1], L2[MODE ? 64 * 65 : 1];
-  const int b = blockIdx.z, t = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, lr = lane & 15,
-            lq = lane >> 4;
+  if (MODE == 1 && blockIdx.x == 0)
+    tl_finish(w.lpart, w.cnt, fin.loss_n, fin.loss, fin.pos_num, fin.pos_mean, fin.B, N, fin.strips, P, ring);
+  const int t = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, lr = lane & 15, lq = lane >> 4;
   const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
   const size_t R = (size_t)C * P, Q = (size_t)P * P;
+  const int nt = (P + 63) / 64;
+  int b, rem;
+  xcd_item(nt * (nt + 1) / 2, fin.B, b, rem);
   const pixpro_dir& dd = D.d[b / N];
   const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  // tile pair index -> (ti <= tj)
+  int ti = 0;
+  while (rem >= nt - ti) { rem -= nt - ti; ++ti; }
+  const int tj = ti + rem, i0 = ti * 64, j0 = tj * 64;
+  float* T0 = ring;                 // tile (ti, tj), [row][EPS]
+  float* T1 = ring + 64 * EPS;      // tile (tj, ti)
   if (MODE == 0) {
-    // S is symmetric: only the tiles (ti <= tj) are computed (10 of 16 at P = 196) and written twice, the mirror image
-    // as one float4 per lane (four consecutive rows of the accumulator are four consecutive columns of the mirror; P % 4 == 0)
-    const int nt = (P + 63) / 64;
-    int ti = 0, rem = blockIdx.x;
-    while (rem >= nt - ti) { rem -= nt - ti; ++ti; }
-    const int tj = ti + rem, m0 = ti * 64, n0 = tj * 64;
+    // S is symmetric: only the tiles (ti <= tj) are computed (10 of 16 at P = 196) and written twice.  Round 3: both
+    // images leave through LDS - the accumulator layout (16 columns x 4 rows per lane group) stored 64-B pieces of four
+    // rows per instruction, the mirror image 16-B pieces of 64 rows; now every store instruction writes four 256-B rows.
     const float* x = dd.x + (size_t)(b % N) * R;
-    f32x4 acc[2][2] = {{z, z}, {z, z}};
-    gram_tile(acc, x, x, m0, n0, C, P, As, Bs);
+    f32x4 acc[1][2][2] = {{{z, z}, {z, z}}};
+    const GramOp op[1] = {{x, x, i0, j0}};
+    gram_core<1>(acc, op, C, P, ring);
     const float* rx = w.rx + (size_t)b * P;
     const float* rv = w.rv + (size_t)b * P;
+    float a[2][2][4], d[2][2][4], rvm[2][4], rvn[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) rvn[j] = rv[min(j0 + wn + 16 * j + lr, P - 1)];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) rvm[i][r] = rv[min(i0 + wm + 16 * i + 4 * lq + r, P - 1)];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const int gn = n0 + wn + 16 * j + lr, gm0 = m0 + wm + 16 * i + 4 * lq;
-        if (gn >= P || gm0 >= P) continue;
-        const float rxn = rx[gn], rvn = rv[gn];
-        float a[4], d[4];
+        const float rxn = rx[min(j0 + wn + 16 * j + lr, P - 1)];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int gm = gm0 + r;
-          pow_map(acc[i][j][r] * rx[gm] * rxn, p, clampv, a[r], d[r]);
-          w.A[(size_t)b * Q + (size_t)gm * P + gn] = a[r];
-          w.Dm[(size_t)b * Q + (size_t)gm * P + gn] = d[r];
-          // the 1/||v|| of Y = v^ A folded into A's rows, so that the strip product stages v as it is
-          w.Av[(size_t)b * Q + (size_t)gm * P + gn] = rv[gm] * a[r];
-        }
-        if (ti != tj) {
-          const size_t o = (size_t)b * Q + (size_t)gn * P + gm0;
-          *reinterpret_cast<float4*>(w.A + o) = make_float4(a[0], a[1], a[2], a[3]);
-          *reinterpret_cast<float4*>(w.Dm + o) = make_float4(d[0], d[1], d[2], d[3]);
-          *reinterpret_cast<float4*>(w.Av + o) = make_float4(rvn * a[0], rvn * a[1], rvn * a[2], rvn * a[3]);
-        }
+        for (int r = 0; r < 4; ++r)
+          pow_map(acc[0][i][j][r] * rx[min(i0 + wm + 16 * i + 4 * lq + r, P - 1)] * rxn, p, clampv, a[i][j][r], d[i][j][r]);
       }
+    // which = 0: A;  1: D = dA/dS;  2: Av[n][k] = rv[k] A[n][k] (the 1/||v|| of Y = v^ A on the COLUMNS: row n of the
+    // stored matrix is column n of the operand of the strip product)
+#pragma unroll
+    for (int which = 0; which < 3; ++which) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          float v[4], m[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            v[r] = which == 0 ? a[i][j][r] : which == 1 ? d[i][j][r] : rvn[j] * a[i][j][r];
+            m[r] = which == 0 ? a[i][j][r] : which == 1 ? d[i][j][r] : rvm[i][r] * a[i][j][r];
+            T0[(wm + 16 * i + 4 * lq + r) * EPS + wn + 16 * j + lr] = v[r];
+          }
+          if (ti != tj)      // mirror image: four consecutive rows of the accumulator = four consecutive columns there
+            *reinterpret_cast<float4*>(T1 + (wn + 16 * j + lr) * EPS + wm + 16 * i + 4 * lq) = make_float4(m[0], m[1], m[2], m[3]);
+        }
+      lds_barrier();
+      float* dst = (which == 0 ? w.A : which == 1 ? w.Dm : w.Av) + (size_t)b * Q;
+      tile_rows_out(T0, dst, i0, j0, P);
+      if (ti != tj) tile_rows_out(T1, dst, j0, i0, P);
+      lds_barrier();
+    }
   } else {
-    // pair index -> (ti <= tj)
-    const int nt = (P + 63) / 64;
-    int ti = 0, rem = blockIdx.x;
-    while (rem >= nt - ti) { rem -= nt - ti; ++ti; }
-    const int tj = ti + rem, i0 = ti * 64, j0 = tj * 64;
+    // dS1[i][j] = rv[j] * sum_c dY[c][i] v[c][j] * D[i][j] on tile (ti, tj), dS2 likewise on tile (tj, ti): both products in
+    // ONE pass over C (round 2 ran them one after the other: two pipeline fills, a third of the occupancy for the partner
+    // tile kept in LDS meanwhile); the diagonal tiles need one product only.
     const float* dY = w.dY + (size_t)b * R;
     const float* v = dd.v + (size_t)(b % N) * R;
     const float* rv = w.rv + (size_t)b * P;
     const float* Dm = w.Dm + (size_t)b * Q;
-    // dS1[i][j] = rv[j] * sum_c dY[c][i] v[c][j] * D[i][j] on tile (ti, tj); dS2 likewise on tile (tj, ti)
+    f32x4 acc[2][2][2] = {{{z, z}, {z, z}}, {{z, z}, {z, z}}};
+    if (ti != tj) {
+      const GramOp op[2] = {{dY, v, i0, j0}, {dY, v, j0, i0}};
+      gram_core<2>(acc, op, C, P, ring);
+    } else {
+      f32x4 one[1][2][2] = {{{z, z}, {z, z}}};
+      const GramOp op[1] = {{dY, v, i0, j0}};
+      gram_core<1>(one, op, C, P, ring);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[0][i][j] = one[0][i][j];
+    }
+#pragma unroll
     for (int half = 0; half < 2; ++half) {
-      const int m0 = half ? j0 : i0, n0 = half ? i0 : j0;
-      float* Lt = half ? L2 : L1;
       if (half && ti == tj) break;
-      f32x4 acc[2][2] = {{z, z}, {z, z}};
-      gram_tile(acc, dY, v, m0, n0, C, P, As, Bs);
+      const int m0 = half ? j0 : i0, n0 = half ? i0 : j0;
+      float* Lt = half ? T1 : T0;
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -324,80 +469,118 @@ __global__ void __launch_bounds__(TB) k_tl_gram(Dirs D, TlWs w, int N, int C, in
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int lm = wm + 16 * i + 4 * lq + r, gm = m0 + lm;
-            Lt[lm * 65 + ln] = (gm < P && gn < P) ? acc[i][j][r] * rvn * Dm[(size_t)gm * P + gn] : 0.f;
+            Lt[lm * EPS + ln] = (gm < P && gn < P) ? acc[half][i][j][r] * rvn * Dm[(size_t)gm * P + gn] : 0.f;
           }
         }
     }
-    __syncthreads();
-    const float* T2 = ti == tj ? L1 : L2;
+    lds_barrier();
+    const float* T2 = ti == tj ? T0 : T1;
     float* out = w.dSs + (size_t)b * Q;
-    const float* rx = w.rx + (size_t)b * P;     // the 1/||x|| of dX^ = x^ dSs folded into the rows of dSs
+    const float* rx = w.rx + (size_t)b * P;     // the 1/||x|| of dX^ = x^ dSs folded into the COLUMNS of the stored dSs
     for (int e = t; e < 64 * 64; e += TB) {
       const int r = e >> 6, c = e & 63;
-      if (i0 + r < P && j0 + c < P) out[(size_t)(i0 + r) * P + j0 + c] = rx[i0 + r] * (L1[r * 65 + c] + T2[c * 65 + r]);
+      if (i0 + r < P && j0 + c < P) out[(size_t)(i0 + r) * P + j0 + c] = rx[j0 + c] * (T0[r * EPS + c] + T2[c * EPS + r]);
       if (ti != tj && j0 + r < P && i0 + c < P)
-        out[(size_t)(j0 + r) * P + i0 + c] = rx[j0 + r] * (L2[r * 65 + c] + L1[c * 65 + r]);
+        out[(size_t)(j0 + r) * P + i0 + c] = rx[i0 + c] * (T1[r * EPS + c] + T0[c * EPS + r]);
     }
   }
 }
 
 // ---- C x 64 strips over K = P: all C rows of a strip of columns in one work-group -----------------------------------------
 // acc[mt][nt] += sum_k Aop(c, k) * Bop(k, n);  wave w owns rows [w*C/4, (w+1)*C/4) = MW 16-row tiles.
-// FA(c, k4): float4 of A for k = 4*k4 .. 4*k4+3 (k-fast source rows);  FB(k, n): scalar of B.
-template <int MW, class FB>
-__device__ __forceinline__ void strip_gemm(f32x4 (&acc)[MW][4], int P, int nlive, float* As, float* Bs,
-                                           const float* __restrict__ Asrc, FB fb) {
-  // A operand: rows of Asrc ([64*MW][P], k-contiguous) as they are (every column scale of the products is folded into the
-  // P x P operand, see k_tl_gram).  A slab in LDS as [row][k], 20 floats per row: four lanes fetch one row's 64 B (16 full
-  // segments per wave instruction) and store them as one 16-B LDS write; the MFMA operand reads are 2-way conflicted
-  // (rows r and r + 8 share banks), which at 8 reads per 16 MFMAs does not show.
-  constexpr int TSA = 20;
+//
+// Round 3.  BOTH operands are k-contiguous in memory: the A operand is a [C][P] tile (v, k, dY, x); the B operands are the
+// P x P matrices, which are symmetric (A, dS + dS^T) up to a scaling the producer (k_tl_gram) applies to the COLUMNS of what
+// it stores, so that row n of the stored matrix is column n of the operand.  Slabs of 16 k arrive by LDS-DMA two slabs
+// ahead in a ring of three, one barrier per slab, no staging registers and no LDS commit instructions (round 2: registers,
+// ds_write, two barriers per slab; the in-loop loads cost a quarter of the kernel).  Slab image [row][16 k]: a lane of the
+// MFMA layout (row lr, k group lq) takes its four k-steps' values k = 4 lq .. 4 lq + 3 with ONE ds_read_b128 (the order of
+// the contraction index is free as long as both operands agree), 8 LDS reads per 64 MFMAs instead of 32.  The 16-B chunk
+// that holds k group q of row r sits at position q ^ g(r), g(r) = (-(r >> 2)) & 3: with that every ds_read_b128 lane group
+// ({0-3,12-15,20-27}, ...) touches each bank once.  The expanded mask bits of G = k^ M^T are written in the same image.
+constexpr int SK = 16, SNB = 3;
+__device__ __forceinline__ int chunk_swz(int row) { return (-(row >> 2)) & 3; }
+
+template <int MW>
+struct StripRing {                            // LDS carve of one strip work-group
+  static constexpr int A_FLOATS = 64 * MW * SK, B_FLOATS = 64 * SK, SLAB = A_FLOATS + B_FLOATS;
+};
+
+// BMODE 0: B rows by DMA from Bsrc (row n0 + n of a [P][P] matrix);  BMODE 1: B generated by `gen(k0, slab B buffer)`.
+template <int MW, int BMODE, class Gen>
+__device__ __forceinline__ void strip_gemm(f32x4 (&acc)[MW][4], int P, int n0, int nlive, float* ring,
+                                           const float* __restrict__ Asrc, const float* __restrict__ Bsrc,
+                                           const float* __restrict__ zero16, Gen gen) {
+  using R = StripRing<MW>;
   const int t = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, lr = lane & 15, lq = lane >> 4;
-  const int arow = t >> 2, ak4 = t & 3;      // + 64 rows per pass, MW passes
-  const int bcol = t & 63, bk = t >> 6;
-  const float4* ap[MW];                      // this thread's float4 of the current slab, advanced by 4 float4 per slab
+  // DMA pieces of this wave: A piece e covers rows 64 e + 16 wave .. + 15 (lane -> row lane >> 2, position lane & 3);
+  // the one B piece covers B rows 16 wave .. + 15
+  const float* pa[MW];
+  int qa[MW];                                  // source k chunk of this lane (position ^ swizzle)
 #pragma unroll
-  for (int e = 0; e < MW; ++e) ap[e] = reinterpret_cast<const float4*>(Asrc + (size_t)(arow + 64 * e) * P) + ak4;
-  float4 ra[MW];
-  float rb[4];
-  const int K4 = P / 4;
-  auto request = [&](int k0) {
-    const bool full = k0 + 16 <= P;          // uniform: only the last slab of P = 196 checks bounds
+  for (int e = 0; e < MW; ++e) {
+    const int row = 64 * e + 16 * wave + (lane >> 2);
+    qa[e] = (lane & 3) ^ chunk_swz(row);
+    pa[e] = Asrc + (size_t)row * P + 4 * qa[e];
+  }
+  const int brow = 16 * wave + (lane >> 2), qb = (lane & 3) ^ chunk_swz(brow);
+  const float* pb = Bsrc + (size_t)min(n0 + brow, P - 1) * P + 4 * qb;   // rows beyond P: finite duplicates, never stored
+  const int S = (P + SK - 1) / SK;
+  auto issue = [&](int s) {
+    float* buf = ring + (s % SNB) * R::SLAB;
+    const int k0 = s * SK;
+    const bool tail = k0 + SK > P;             // uniform: only the last slab of P = 196 has k chunks beyond P
 #pragma unroll
-    for (int e = 0; e < MW; ++e) {
-      ra[e] = (full || k0 / 4 + ak4 < K4) ? *ap[e] : make_float4(0.f, 0.f, 0.f, 0.f);
-      ap[e] += 4;
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int k = k0 + bk + 4 * e;
-      rb[e] = (full || k < P) ? fb(k, bcol) : 0.f;
-    }
+    for (int e = 0; e < MW; ++e)
+      dma16((tail && k0 + 4 * qa[e] >= P) ? zero16 : pa[e] + k0, buf + (64 * e + 16 * wave) * SK);
+    if (BMODE == 0) dma16((tail && k0 + 4 * qb >= P) ? zero16 : pb + k0, buf + R::A_FLOATS + 16 * wave * SK);
   };
-  request(0);
-  for (int k0 = 0; k0 < P; k0 += 16) {
+  constexpr int PER = MW + (BMODE == 0 ? 1 : 0);       // copies per wave and slab
+  issue(0);
+  if (BMODE == 1) gen(0, ring + R::A_FLOATS);
+  if (S > 1) {
+    issue(1);
+    if (BMODE == 1) gen(SK, ring + R::SLAB + R::A_FLOATS);
+  }
+  // fragment addresses inside a slab (floats): A row wave*16MW + 16m + lr, B row 16nn + lr, k group lq
+  int fa[MW], fb[4];
 #pragma unroll
-    for (int e = 0; e < MW; ++e) *reinterpret_cast<float4*>(&As[(arow + 64 * e) * TSA + 4 * ak4]) = ra[e];
+  for (int m = 0; m < MW; ++m) {
+    const int row = wave * 16 * MW + 16 * m + lr;
+    fa[m] = row * SK + 4 * (lq ^ chunk_swz(row));
+  }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) Bs[(bk + 4 * e) * TSB + bcol] = rb[e];
-    __syncthreads();
-    if (k0 + 16 < P) request(k0 + 16);     // the next slab travels under the MFMAs of this one
+  for (int nn = 0; nn < 4; ++nn) {
+    const int row = 16 * nn + lr;
+    fb[nn] = R::A_FLOATS + row * SK + 4 * (lq ^ chunk_swz(row));
+  }
+  for (int s = 0; s < S; ++s) {
+    if (TL_ABL & 4) wait_vm<0>();
+    else if (s + 1 < S) wait_vm<PER>(); else wait_vm<0>();   // this wave's copies of slab s have landed
+    lds_barrier();                                      // ... everybody's; and slab s - 1 has been read by everybody
+    if (s + 2 < S && !(TL_ABL & 4)) {
+      issue(s + 2);
+      if (BMODE == 1) gen((s + 2) * SK, ring + ((s + 2) % SNB) * R::SLAB + R::A_FLOATS);
+    }
+    const float* buf = ring + (s % SNB) * R::SLAB;
+    float4 av[MW], bv[4];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      float av[MW], bv[4];
+    for (int m = 0; m < MW; ++m) av[m] = *reinterpret_cast<const float4*>(buf + fa[m]);
 #pragma unroll
-      for (int m = 0; m < MW; ++m) av[m] = As[(wave * 16 * MW + 16 * m + lr) * TSA + 4 * ks + lq];
+    for (int nn = 0; nn < 4; ++nn) bv[nn] = *reinterpret_cast<const float4*>(buf + fb[nn]);
 #pragma unroll
-      for (int nn = 0; nn < 4; ++nn) bv[nn] = Bs[(4 * ks + lq) * TSB + 16 * nn + lr];
+    for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
       for (int nn = 0; nn < 4; ++nn)
-        if (nn < nlive) {                // column tiles wholly beyond P issue no MFMA (uniform)
+        if (nn < nlive) {                // column tiles beyond this strip issue no MFMA (uniform)
 #pragma unroll
-          for (int m = 0; m < MW; ++m) acc[m][nn] = mfma16(av[m], bv[nn], acc[m][nn]);
+          for (int m = 0; m < MW; ++m)
+            if (TL_ABL & 2) acc[m][nn][0] += (ks == 0 ? av[m].x : ks == 1 ? av[m].y : ks == 2 ? av[m].z : av[m].w) + bv[nn].x;
+            else acc[m][nn] = mfma16(ks == 0 ? av[m].x : ks == 1 ? av[m].y : ks == 2 ? av[m].z : av[m].w,
+                                ks == 0 ? bv[nn].x : ks == 1 ? bv[nn].y : ks == 2 ? bv[nn].z : bv[nn].w, acc[m][nn]);
         }
-    }
-    __syncthreads();
   }
+  lds_barrier();                                        // the ring may be refilled by the next product
 }
 
 // column sums over all C rows of v[nn] (this lane's columns 16*nn + lr): shuffles over lq, one LDS hop over the 4 waves
@@ -416,19 +599,75 @@ __device__ __forceinline__ void strip_colsum(float (&v)[4], float* part) {
   __syncthreads();
 }
 
-// MODE 0: forward + loss + dY (grid: strips, B, 1).  MODE 1 / 2: dv / dx (grid: strips, B, 2; blockIdx.z selects).
+// MODE 0: forward + loss + dY (grid: B * strips).  MODE 1: dv / dx (grid: B * 2 strips; the item index selects).
 template <int MW, int MODE>
-__global__ void __launch_bounds__(TB) k_tl_strip(pixpro_problem pb, Dirs D, TlWs w, float g0, int want_grad) {
+__global__ void __launch_bounds__(TB) k_tl_strip(pixpro_problem pb, Dirs D, TlWs w, float g0, int want_grad, int ns) {
   constexpr int C = 64 * MW;
-  __shared__ __attribute__((aligned(16))) float As[C * 20];
-  __shared__ float Bs[16 * TSB];
+  __shared__ __attribute__((aligned(16))) float ring[SNB * StripRing<MW>::SLAB];      // 60 KB at C = 256
   __shared__ float part[4 * 64];
-  const int b = blockIdx.y, N = pb.N, P = pb.H * pb.W, n0 = blockIdx.x * 64, W64 = (P + 63) / 64;
+  __shared__ unsigned long long bl[MODE == 0 ? 64 * (TL_MAXP / 64) : 1];             // the strip's mask bit rows
+  __shared__ float rks[MODE == 0 ? TL_MAXP + SK : 1];                                // 1/||k_j||, zero beyond P
+  const int N = pb.N, P = pb.H * pb.W, W64 = (P + 63) / 64;
   const int t = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, lr = lane & 15, lq = lane >> 4;
   const size_t R = (size_t)C * P, Q = (size_t)P * P;
+  int b, item;                                  // item = strip (+ ns for the dx half of MODE 1)
+  xcd_item(MODE == 0 ? ns : 2 * ns, N * pb.ndir, b, item);
+  const int sx = item % ns;
   const pixpro_dir& dd = D.d[b / N];
   const size_t so = (size_t)(b % N) * R;
-  const int nlive = min(4, (P - n0 + 15) / 16);
+  // The 16-column tiles of P are dealt evenly to the strips, larger strips first (P = 196: 13 tiles as 4 + 3 + 3 + 3;
+  // round 2 cut 64-column strips, 4 + 4 + 4 + 1: the CUs holding the one-tile strips idled for most of the launch).
+  int n0, nlive;
+  {
+    const int tt = (P + 15) / 16, base = tt / ns, rem = tt % ns;
+    n0 = 16 * (sx * base + min(sx, rem));
+    nlive = base + (sx < rem ? 1 : 0);
+  }
+  const int pend = min(P, n0 + 16 * nlive);     // this strip's columns are [n0, pend): the epilogues touch nothing beyond
+  // Global traffic of the epilogues goes through a per-wave staging tile in the (idle) ring: the accumulator layout (16
+  // columns x 4 rows per lane group) would load / store 64-B pieces of four rows per instruction - measured at 56 us of
+  // the 141 us of k_tl_strip<1>; staged, every instruction moves four rows of up to 256 B, 16 B per lane.  Same wave
+  // writes and reads its tile (LDS operations of a wave execute in order): no barrier.
+  constexpr int MC = MW >= 2 ? 2 : 1;           // 16-row tiles per staging pass
+  static_assert(SNB * StripRing<MW>::SLAB >= 4 * 16 * MC * EPS, "staging tiles fit in the ring");
+  float* scr = ring + wave * (16 * MC * EPS);
+  auto rows_out = [&](float* __restrict__ dst, auto value) {      // value(m, nn, r) in accumulator layout -> rows of dst
+#pragma unroll
+    for (int pp = 0; pp < MW / MC; ++pp) {
+#pragma unroll
+      for (int mm = 0; mm < MC; ++mm)
+#pragma unroll
+        for (int nn = 0; nn < 4; ++nn)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) scr[(16 * mm + 4 * lq + r) * EPS + 16 * nn + lr] = value(MC * pp + mm, nn, r);
+#pragma unroll
+      for (int i = 0; i < 4 * MC; ++i) {
+        const int row = 4 * i + (lane >> 4), c4 = lane & 15;
+        if (n0 + 4 * c4 < pend)
+          *reinterpret_cast<float4*>(dst + (size_t)(wave * 16 * MW + 16 * MC * pp + row) * P + n0 + 4 * c4) =
+              *reinterpret_cast<const float4*>(scr + row * EPS + 4 * c4);
+      }
+    }
+  };
+  auto rows_in = [&](const float* __restrict__ src, auto sink) {   // rows of src -> sink(m, nn, r, value)
+#pragma unroll
+    for (int pp = 0; pp < MW / MC; ++pp) {
+#pragma unroll
+      for (int i = 0; i < 4 * MC; ++i) {
+        const int row = 4 * i + (lane >> 4), c4 = lane & 15;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n0 + 4 * c4 < pend)
+          v = *reinterpret_cast<const float4*>(src + (size_t)(wave * 16 * MW + 16 * MC * pp + row) * P + n0 + 4 * c4);
+        *reinterpret_cast<float4*>(scr + row * EPS + 4 * c4) = v;
+      }
+#pragma unroll
+      for (int mm = 0; mm < MC; ++mm)
+#pragma unroll
+        for (int nn = 0; nn < 4; ++nn)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sink(MC * pp + mm, nn, r, scr[(16 * mm + 4 * lq + r) * EPS + 16 * nn + lr]);
+    }
+  };
   const f32x4 z = {0.f, 0.f, 0.f, 0.f};
   auto crow = [&](int m, int r) { return wave * 16 * MW + 16 * m + 4 * lq + r; };
   f32x4 acc[MW][4];
@@ -440,13 +679,18 @@ __global__ void __launch_bounds__(TB) k_tl_strip(pixpro_problem pb, Dirs D, TlWs
   if (MODE == 0) {
     const float* v = dd.v + so;
     const float* kk = dd.k + so;
-    const float* rv = w.rv + (size_t)b * P;
     const float* rk = w.rk + (size_t)b * P;
     const float* Av = w.Av + (size_t)b * Q;
-    (void)rv;
-    // ---- Y = v^ A = v (diag(rv) A): the column scale of v sits in the rows of Av, the loader is a plain copy
-    const bool cok = n0 + (t & 63) < P;        // this loader thread's column exists
-    strip_gemm<MW>(acc, P, nlive, As, Bs, v, [&](int k, int nl) { return cok ? Av[(size_t)k * P + n0 + nl] : 0.f; });
+    // ---- Y = v^ A = v (diag(rv) A): the scale sits in the COLUMNS of the stored matrix AvT[n][k] = rv[k] A[n][k] (A is
+    // symmetric), whose row n is column n of the operand: both operands stream k-contiguous, as they are
+    // stage what the G product needs while the first copies travel: the strip's bit rows and 1/||k||
+    for (int e = t; e < 64 * W64; e += TB) {
+      const int n = e / W64, wd = e - n * W64;
+      bl[e] = n0 + n < P ? w.bits[((size_t)b * P + n0 + n) * W64 + wd] : 0ull;
+    }
+    for (int e = t; e < P + SK; e += TB) rks[e] = e < P ? rk[e] : 0.f;
+    auto none = [](int, float*) {};
+    strip_gemm<MW, 0>(acc, P, n0, nlive, ring, v, Av, w.zero, none);
     float ry[4];
     {
       float s[4];
@@ -470,16 +714,8 @@ __global__ void __launch_bounds__(TB) k_tl_strip(pixpro_problem pb, Dirs D, TlWs
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[m][nn][r] = acc[m][nn][r] * ry[nn];
     if (dd.pred) {
-      float* gp = dd.pred + so;
-#pragma unroll
-      for (int m = 0; m < MW; ++m)
-#pragma unroll
-        for (int nn = 0; nn < 4; ++nn) {
-          const int i = n0 + 16 * nn + lr;
-          if (i < P)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) gp[(size_t)crow(m, r) * P + i] = acc[m][nn][r];
-        }
+      rows_out(dd.pred + so, [&](int m, int nn, int r) { return acc[m][nn][r]; });
+      lds_barrier();             // the staging tiles lie where the next product's first slabs land
     }
     // ---- G = k^ M^T, M expanded from the bit rows: B(k = j, n = i) = bit j of row i
     f32x4 G[MW][4];
@@ -487,11 +723,16 @@ __global__ void __launch_bounds__(TB) k_tl_strip(pixpro_problem pb, Dirs D, TlWs
     for (int m = 0; m < MW; ++m)
 #pragma unroll
       for (int nn = 0; nn < 4; ++nn) G[m][nn] = z;
-    const unsigned long long* brow = w.bits + ((size_t)b * P + min(n0 + (t & 63), P - 1)) * W64;
-    const bool bok = n0 + (t & 63) < P;
-    // G = k^ M^T = k (diag(rk) M^T): the column scale of k rides on the expanded mask bits
-    strip_gemm<MW>(G, P, nlive, As, Bs, kk,
-                   [&](int k, int) { return (bok && ((brow[k >> 6] >> (k & 63)) & 1ull)) ? rk[k] : 0.f; });
+    // G = k^ M^T = k (diag(rk) M^T): the column scale of k rides on the expanded mask bits.  Thread (n = t & 63, k group
+    // t >> 6) writes the four values of its k group as one 16-B store into the slab image (same swizzle as the copies).
+    const int gn = t & 63, gq = t >> 6, gofs = gn * SK + 4 * (gq ^ chunk_swz(gn));
+    auto gen = [&](int k0, float* Bbuf) {
+      const int k = k0 + 4 * gq;                                       // < P + SK: rks is zero there, the bits too
+      const unsigned m4 = k < 64 * W64 ? (unsigned)(bl[gn * W64 + (k >> 6)] >> (k & 63)) & 15u : 0u;
+      *reinterpret_cast<float4*>(Bbuf + gofs) = make_float4((m4 & 1u) ? rks[k] : 0.f, (m4 & 2u) ? rks[k + 1] : 0.f,
+                                                            (m4 & 4u) ? rks[k + 2] : 0.f, (m4 & 8u) ? rks[k + 3] : 0.f);
+    };
+    strip_gemm<MW, 1>(G, P, n0, nlive, ring, kk, nullptr, w.zero, gen);
     // ---- <Y^, G> per column, loss partial, dY
     float tc[4];
 #pragma unroll
@@ -507,63 +748,40 @@ __global__ void __launch_bounds__(TB) k_tl_strip(pixpro_problem pb, Dirs D, TlWs
     if (wave == 0) {
       float s = 0.f;
 #pragma unroll
-      for (int nn = 0; nn < 4; ++nn) s += (lane < 16 && n0 + 16 * nn + lr < P) ? tc[nn] : 0.f;
+      for (int nn = 0; nn < 4; ++nn) s += (lane < 16 && n0 + 16 * nn + lr < pend) ? tc[nn] : 0.f;
       s = wave_sum(s);
-      if (lane == 0) w.lpart[(size_t)b * gridDim.x + blockIdx.x] = s;
+      if (lane == 0) w.lpart[(size_t)b * ns + sx] = s;
     }
     if (!want_grad) return;
     const float gs = g0 / (w.cnt[b] + 1e-6f);
-    float* dY = w.dY + (size_t)b * R;
+    float tg[4];
 #pragma unroll
-    for (int nn = 0; nn < 4; ++nn) {
-      const int i = n0 + 16 * nn + lr;
-      if (i < P) {
-        const float ti = gs * tc[nn], ryv = ry[nn];
-#pragma unroll
-        for (int m = 0; m < MW; ++m)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) dY[(size_t)crow(m, r) * P + i] = (gs * G[m][nn][r] - acc[m][nn][r] * ti) * ryv;
-      }
-    }
+    for (int nn = 0; nn < 4; ++nn) tg[nn] = gs * tc[nn];
+    rows_out(w.dY + (size_t)b * R,
+             [&](int m, int nn, int r) { return (gs * G[m][nn][r] - acc[m][nn][r] * tg[nn]) * ry[nn]; });
   } else {
-    // blockIdx.z = 0: dV^ = dY A, dv = (dV^ - v^ s) / n_v ;  blockIdx.z = 1: dX^ = x^ dSs', dx = (dX^ - x^ s) / n_x
+    // item < ns: dV^ = dY A, dv = (dV^ - v^ s) / n_v ;  item >= ns: dX^ = x^ dSs', dx = (dX^ - x^ s) / n_x
     // (both products in one work-group - a loop over the two - compiles to 256 VGPRs and runs slower: 204 us vs 127 us)
-    const bool isx = blockIdx.z == 1;
+    const bool isx = item >= ns;
     const float* src = (isx ? dd.x : dd.v) + so;               // the tensor being differentiated
     const float* rn = (isx ? w.rx : w.rv) + (size_t)b * P;
     const float* Mat = (isx ? w.dSs : w.A) + (size_t)b * Q;
     const float* Aop = isx ? src : w.dY + (size_t)b * R;
-    const bool cok = n0 + (t & 63) < P;
-    strip_gemm<MW>(acc, P, nlive, As, Bs, Aop, [&](int k, int nl) { return cok ? Mat[(size_t)k * P + n0 + nl] : 0.f; });
+    auto none = [](int, float*) {};
+    strip_gemm<MW, 0>(acc, P, n0, nlive, ring, Aop, Mat, w.zero, none);
     float hat[MW][4][4];
-    float s[4];
+    float s[4] = {0.f, 0.f, 0.f, 0.f}, rj[4];
 #pragma unroll
-    for (int nn = 0; nn < 4; ++nn) {
-      const int j = n0 + 16 * nn + lr;
-      const float rj = j < P ? rn[j] : 0.f;
-      float a = 0.f;
-#pragma unroll
-      for (int m = 0; m < MW; ++m)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          hat[m][nn][r] = j < P ? src[(size_t)crow(m, r) * P + j] * rj : 0.f;
-          a = __builtin_fmaf(hat[m][nn][r], acc[m][nn][r], a);
-        }
-      s[nn] = a;
-    }
+    for (int nn = 0; nn < 4; ++nn) rj[nn] = n0 + 16 * nn + lr < pend ? rn[n0 + 16 * nn + lr] : 0.f;
+    if (!(TL_ABL & 1))
+      rows_in(src, [&](int m, int nn, int r, float val) {
+        hat[m][nn][r] = val * rj[nn];
+        s[nn] = __builtin_fmaf(hat[m][nn][r], acc[m][nn][r], s[nn]);
+      });
     strip_colsum(s, part);
-    float* out = (isx ? dd.dx : dd.dv) + so;
-#pragma unroll
-    for (int nn = 0; nn < 4; ++nn) {
-      const int j = n0 + 16 * nn + lr;
-      if (j < P) {
-        const float sj = s[nn], rj = rn[j];
-#pragma unroll
-        for (int m = 0; m < MW; ++m)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) out[(size_t)crow(m, r) * P + j] = (acc[m][nn][r] - hat[m][nn][r] * sj) * rj;
-      }
-    }
+    if (!(TL_ABL & 1) || s[0] == 123.456f)
+      rows_out((isx ? dd.dx : dd.dv) + so,
+               [&](int m, int nn, int r) { return (acc[m][nn][r] - hat[m][nn][r] * s[nn]) * rj[nn]; });
   }
 }
 
@@ -588,22 +806,23 @@ int run_tiled_c(const pixpro_problem& pb, const Dirs& D, const TlWs& w, float* l
   const bool want_grad = D.d[0].dx != nullptr;
   const float g0 = pb.grad_scale * -2.f / (float)N;
   const TlFin fin{loss_n, loss, pos_num, pos_mean, B, nt};
-  hipLaunchKernelGGL(k_tl_rnorms, dim3(nt, B, 3), dim3(TB), 0, st, D, w.rx, w.rv, w.rk, w.cnt, N, C, P, pb.normalize_k);
+  hipLaunchKernelGGL(k_tl_rnorms, dim3(nt, B, 3), dim3(TB), 0, st, D, w.rx, w.rv, w.rk, w.cnt, w.zero, N, C, P,
+                     pb.normalize_k);
   TL_CHECK("k_tl_rnorms");                 // also zeroes the counts k_tl_prep accumulates
   hipLaunchKernelGGL(k_tl_prep, dim3(B, PREP_S), dim3(TB), 0, st, pb, D, w.bits, w.cnt);
   TL_CHECK("k_tl_prep");
-  hipLaunchKernelGGL(k_tl_gram<0>, dim3(nt * (nt + 1) / 2, 1, B), dim3(TB), 0, st, D, w, N, C, P, pb.p, pb.clamp, fin);
+  hipLaunchKernelGGL(k_tl_gram<0>, dim3(nt * (nt + 1) / 2 * B), dim3(TB), 0, st, D, w, N, C, P, pb.p, pb.clamp, fin);
   TL_CHECK("k_tl_gram<0>");
-  hipLaunchKernelGGL((k_tl_strip<MW, 0>), dim3(nt, B, 1), dim3(TB), 0, st, pb, D, w, g0, (int)want_grad);
+  hipLaunchKernelGGL((k_tl_strip<MW, 0>), dim3(nt * B), dim3(TB), 0, st, pb, D, w, g0, (int)want_grad, nt);
   TL_CHECK("k_tl_strip<0>");
   if (!want_grad) {
     hipLaunchKernelGGL(k_tl_finish, dim3(1), dim3(TB), 0, st, w.lpart, w.cnt, loss_n, loss, pos_num, pos_mean, B, N, nt, P);
     TL_CHECK("k_tl_finish");
     return PIXPRO_OK;
   }
-  hipLaunchKernelGGL(k_tl_gram<1>, dim3(nt * (nt + 1) / 2, 1, B), dim3(TB), 0, st, D, w, N, C, P, pb.p, pb.clamp, fin);
+  hipLaunchKernelGGL(k_tl_gram<1>, dim3(nt * (nt + 1) / 2 * B), dim3(TB), 0, st, D, w, N, C, P, pb.p, pb.clamp, fin);
   TL_CHECK("k_tl_gram<1>");
-  hipLaunchKernelGGL((k_tl_strip<MW, 1>), dim3(nt, B, 2), dim3(TB), 0, st, pb, D, w, g0, 1);
+  hipLaunchKernelGGL((k_tl_strip<MW, 1>), dim3(2 * nt * B), dim3(TB), 0, st, pb, D, w, g0, 1, nt);
   TL_CHECK("k_tl_strip<1>");
   return PIXPRO_OK;
 }

@@ -1,7 +1,19 @@
-for d in 0 1 3 7; do
-  export PIXPRO_TL_DBG=$d
-  cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kt_abl$d -- python3 tools/hotpath_bench.py --what ppm --batch 64 --grid 14 > gpurun_out/kt_abl$d.log 2>&1
-  f=$(find gpurun_out/kt_abl$d -name "*kernel_stats.csv" | head -1)
-  echo dbg=$d $(grep "k_tl_strip<4, 0>" $f | awk -F'",' '{print $2}' | cut -d, -f3)
+#!/bin/bash
+# Timing ablations of the tiled path: builds libpixpro_hip variants with -DTL_ABL=n into exp_libs/ (git-ignored) HERE,
+# then on the GPU box: tools/tl_abl.sh run  ->  per-kernel averages per variant.  Results of the variants are wrong by design.
+set -e
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+if [ "$1" != "run" ]; then
+  mkdir -p "$ROOT/exp_libs"
+  for n in "$@"; do
+    /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off -DTL_ABL=$n -c "$ROOT/pixpro-with-opticalflow_amd/csrc/ppm_tiled.hip" -o "$ROOT/exp_libs/ppm_tiled_abl$n.o"
+    objs=$(ls "$ROOT"/pixpro-with-opticalflow_amd/lib/*.o | grep -v ppm_tiled.o)
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$ROOT/exp_libs/libpixpro_abl$n.so" $objs "$ROOT/exp_libs/ppm_tiled_abl$n.o"
+  done
+  exit 0
+fi
+for lib in "$ROOT"/exp_libs/libpixpro_abl*.so; do
+  n=$(basename "$lib" .so)
+  echo "== $n"
+  "$ROOT/tools/tl_prof.sh" "gpurun_out/abl_$n" --lib "$lib" | grep -E "k_tl_|sum"
 done
