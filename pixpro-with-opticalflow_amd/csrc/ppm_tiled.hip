@@ -21,7 +21,8 @@ namespace pixpro {
 namespace {
 
 #ifndef TL_ABL
-#define TL_ABL 0                 // timing ablations (tools/tl_abl.sh): 1 strip<1> epilogue traffic off, 2 no MFMA, 4 no copies
+#define TL_ABL 0                 // timing ablations (tools/tl_abl.sh): strips: 1 strip<1> epilogue traffic off, 2 no MFMA, 4 no copies;
+                                 // Gram kernels: 8 no epilogue stores, 16 no MFMA, 32 no copies after the first two slabs
 #endif
 constexpr int TB = 256;          // threads per work-group: 4 waves
 constexpr int TSB = 80;          // LDS row stride of a 64-wide operand slab (conflict-free MFMA operand reads)
@@ -277,11 +278,15 @@ __device__ __forceinline__ void gram_core(f32x4 (&acc)[NP][2][2], const GramOp (
   if (S > 1) issue(1);
   const int sw = 16 * (lq & 1);
   for (int s = 0; s < S; ++s) {
-    if (s + 1 < S) wait_vm<PER>(); else wait_vm<0>();   // this wave's pieces of slab s have landed
+    if (TL_ABL & 32) wait_vm<0>();
+    else if (s + 1 < S) wait_vm<PER>(); else wait_vm<0>();   // this wave's pieces of slab s have landed
     lds_barrier();                                      // ... everybody's; and everybody is done reading slab s - 1
-    if (s + 2 < S) issue(s + 2);                        // into the buffer slab s - 1 occupied
+    if (s + 2 < S && !(TL_ABL & 32)) issue(s + 2);      // into the buffer slab s - 1 occupied
     const float* buf = ring + (s % GNB) * NP * 2 * SLAB;
-    if (full) {                                         // the common case: straight-line code
+    if (TL_ABL & 16) {
+#pragma unroll
+      for (int q = 0; q < NP; ++q) acc[q][0][0][0] += buf[(2 * q) * SLAB + lane + 64 * (s & 7)] + buf[(2 * q + 1) * SLAB + lane];
+    } else if (full) {                                         // the common case: straight-line code
 #pragma unroll
       for (int ks = 0; ks < GKT / 4; ++ks)
 #pragma unroll
@@ -356,7 +361,7 @@ __device__ __forceinline__ void tile_rows_out(const float* tile, float* __restri
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = 16 * wave + 4 * i + (lane >> 4);
-    if (r0 + row < P && c0 + 4 * c4 < P)
+    if (r0 + row < P && c0 + 4 * c4 < P && (!(TL_ABL & 8) || tile[0] == 123.456f))
       *reinterpret_cast<float4*>(dst + (size_t)(r0 + row) * P + c0 + 4 * c4) =
           *reinterpret_cast<const float4*>(tile + row * EPS + 4 * c4);
   }
@@ -455,22 +460,22 @@ __global__ void __launch_bounds__(TB) k_tl_gram(Dirs D, TlWs w, int N, int C, in
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[0][i][j] = one[0][i][j];
     }
+    // dSs[i][j] = dS[i][j] + dS[j][i] with dS = rv[col] dA o D and D symmetric:  dSs[i][j] = D[i][j] (U1[i][j] + U2[j][i]),
+    // U = rv[col] * dA staged in LDS per tile.  D is read row-major where the result is written (256-B rows); round 2
+    // multiplied by D in the accumulator layout: 32 loads of 64-B pieces of four rows per lane.
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       if (half && ti == tj) break;
-      const int m0 = half ? j0 : i0, n0 = half ? i0 : j0;
+      const int n0 = half ? i0 : j0;
       float* Lt = half ? T1 : T0;
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          const int ln = wn + 16 * j + lr, gn = n0 + ln;
-          const float rvn = gn < P ? rv[gn] : 0.f;
+          const int ln = wn + 16 * j + lr;
+          const float rvn = rv[min(n0 + ln, P - 1)];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int lm = wm + 16 * i + 4 * lq + r, gm = m0 + lm;
-            Lt[lm * EPS + ln] = (gm < P && gn < P) ? acc[half][i][j][r] * rvn * Dm[(size_t)gm * P + gn] : 0.f;
-          }
+          for (int r = 0; r < 4; ++r) Lt[(wm + 16 * i + 4 * lq + r) * EPS + ln] = acc[half][i][j][r] * rvn;
         }
     }
     lds_barrier();
@@ -479,9 +484,15 @@ __global__ void __launch_bounds__(TB) k_tl_gram(Dirs D, TlWs w, int N, int C, in
     const float* rx = w.rx + (size_t)b * P;     // the 1/||x|| of dX^ = x^ dSs folded into the COLUMNS of the stored dSs
     for (int e = t; e < 64 * 64; e += TB) {
       const int r = e >> 6, c = e & 63;
-      if (i0 + r < P && j0 + c < P) out[(size_t)(i0 + r) * P + j0 + c] = rx[j0 + c] * (T0[r * EPS + c] + T2[c * EPS + r]);
-      if (ti != tj && j0 + r < P && i0 + c < P)
-        out[(size_t)(j0 + r) * P + i0 + c] = rx[i0 + c] * (T1[r * EPS + c] + T0[c * EPS + r]);
+      if ((TL_ABL & 8) && T0[0] != 123.456f) continue;
+      if (i0 + r < P && j0 + c < P) {
+        const size_t o = (size_t)(i0 + r) * P + j0 + c;
+        out[o] = rx[j0 + c] * (Dm[o] * (T0[r * EPS + c] + T2[c * EPS + r]));
+      }
+      if (ti != tj && j0 + r < P && i0 + c < P) {
+        const size_t o = (size_t)(j0 + r) * P + i0 + c;
+        out[o] = rx[i0 + c] * (Dm[o] * (T1[r * EPS + c] + T0[c * EPS + r]));
+      }
     }
   }
 }
