@@ -311,14 +311,15 @@ __device__ __forceinline__ bool fbc_cells(float2 fn, const Up8Geom& g, float c0x
 // range wider than the table reaches, or most boxes wider than the tolerance: motion boundaries, occlusions) is left
 // to the staged kernel.  A certified pixel costs one fused up-sampling step per channel, the exact normalisation and
 // ~12 instructions per direction - no taps, no halo.
-constexpr int TYC = 2 * TY;                              // a certified tile = two staged tiles on top of each other
-constexpr int W0_W = TX / 8 + 4, W0_H = TYC / 8 + 4;     // low-res cells under a tile: at most 12 x 14
+constexpr int TYC = 2 * TY;                              // a certified tile = two staged tiles on top of each other ...
+constexpr int TXC = 2 * TX;                              // ... and two side by side: 128 x 80 pixels, a lane owns TWO columns
+constexpr int W0_W = TXC / 8 + 4, W0_H = TYC / 8 + 4;    // low-res cells under a tile: at most 20 x 14
 constexpr int MARG = 4;                                  // cells of margin around them: own flow RANGE up to ~48 px
-constexpr int WW = W0_W + 2 * MARG, WH = W0_H + 2 * MARG;   // cell window: 20 x 22
+constexpr int WW = W0_W + 2 * MARG, WH = W0_H + 2 * MARG;   // cell window: 28 x 22
 constexpr float BOX_SLOP = 1e-5f;
 constexpr uint8_t TILE_MARK = 0xFF;                      // first mask byte of a tile left to k_prepare_staged
 constexpr int NT_C = 320, NWAVE_C = NT_C / 64, ROWS_C = TYC / NWAVE_C;   // 5 waves x 16 rows, lane = column
-static_assert(TYC % NWAVE_C == 0 && 2 * ROWS_C <= 32, "row mapping / deferred-pixel bit mask");
+static_assert(TYC % NWAVE_C == 0 && 4 * ROWS_C <= 64, "row mapping / deferred-pixel bit mask");
 
 __device__ __forceinline__ float wave_min(float v) {
 #pragma unroll
@@ -353,16 +354,22 @@ k_prepare_cert(const float* __restrict__ lo_fwd, const float* __restrict__ lo_bw
                float* __restrict__ flow_bwd, uint8_t* __restrict__ mask_fwd, uint8_t* __restrict__ mask_bwd,
                int32_t* __restrict__ invalid, int N, Up8Geom g, int force) {
   __shared__ float4 cw[WH * WW];           // cells {fwd.x, fwd.y, bwd.x, bwd.y} under the tile + margin, replicate-padded
-  __shared__ float2 tw[2][WH * WW];        // target cells of a DISPLACED window (large coherent motion), per direction
+  // target cells of a DISPLACED window (large coherent motion), per direction: input of the row pass; the table the
+  // column pass writes (two barriers later) takes its place
+  __shared__ __attribute__((aligned(16))) float2 tw_store[2 * WH * WW];
+  static_assert(sizeof(float2) * 2 * WH * WW >= sizeof(float4) * 2 * W0_H * W0_W, "the table fits where the window was");
+  float2 (*tw)[WH * WW] = reinterpret_cast<float2 (*)[WH * WW]>(tw_store);
+  float4 (*tab)[W0_H * W0_W] = reinterpret_cast<float4 (*)[W0_H * W0_W]>(tw_store);   // per own cell: normalised, inflated
+                                           // box {Lx, Ux, Ly, Uy} of the opposite flow
   __shared__ float4 tmp[2][WH * W0_W];     // row pass {min x, max x, min y, max y} of the opposite flow
-  __shared__ float4 tab[2][W0_H * W0_W];   // per own cell: normalised, inflated box {Lx, Ux, Ly, Uy} of the opposite flow
   __shared__ float part0[NWAVE_C][8];      // per-wave {min, max} x 4 channels of the cells under the tile
-  __shared__ int odd_cells, wide_boxes;    // NaN / infinite cell seen (fminf would drop a NaN); boxes beyond the tolerance
+  __shared__ int odd_cells, wide_boxes[2]; // NaN / infinite cell seen (fminf would drop a NaN); boxes beyond the tolerance,
+                                           // per 64-column half of the tile (cells on the seam count for both)
   __shared__ int uni[16];                  // wave 0's block-uniform results: certify, {ox, ex, oy, ey, shx, shy} x 2
   const int n = blockIdx.z, t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int tx0 = blockIdx.x * TX, ty0 = blockIdx.y * TYC;
-  const int tx1 = min(tx0 + TX, g.Wf) - 1, ty1 = min(ty0 + TYC, g.Hf) - 1;     // last pixel of the tile inside the frame
+  const int tx0 = blockIdx.x * TXC, ty0 = blockIdx.y * TYC;
+  const int tx1 = min(tx0 + TXC, g.Wf) - 1, ty1 = min(ty0 + TYC, g.Hf) - 1;    // last pixel of the tile inside the frame
   const size_t hw = (size_t)g.h * g.w, HW = (size_t)g.Hf * g.Wf;
   const float* gf = lo_fwd + (size_t)n * 2 * hw;
   const float* gb = lo_bwd + (size_t)n * 2 * hw;
@@ -370,7 +377,7 @@ k_prepare_cert(const float* __restrict__ lo_fwd, const float* __restrict__ lo_bw
   // ---- the cell window and the range of the tile's own flows
   const int wx0 = axf(tx0, g.sx).i0, wy0 = axf(ty0, g.sy).i0;
   const int ucols = min(axf(tx1, g.sx).i0 + 1, g.w - 1) - wx0 + 1, urows = min(axf(ty1, g.sy).i0 + 1, g.h - 1) - wy0 + 1;
-  if (t == 0) { odd_cells = 0; wide_boxes = 0; }
+  if (t == 0) { odd_cells = 0; wide_boxes[0] = 0; wide_boxes[1] = 0; }
   {
     float mn[4] = {INF, INF, INF, INF}, mx[4] = {-INF, -INF, -INF, -INF};
     bool odd = false;
@@ -394,6 +401,8 @@ k_prepare_cert(const float* __restrict__ lo_fwd, const float* __restrict__ lo_bw
   }
   __syncthreads();
   bool certify = mask_fwd != nullptr && force != 2;       // block-uniform throughout
+  bool cert_h[2] = {false, false};                        // ... per 64-column half, once the tables are built
+  const int c64 = axf(min(tx0 + TX, g.Wf - 1), g.sx).i0 - wx0;   // window column of the cell under the seam
   int shx[2] = {0, 0}, shy[2] = {0, 0};                   // displacement of the target window, in cells
   bool shifted = false;
   if (mask_fwd != nullptr) {                              // uniform: the barriers below are reached by every thread
@@ -494,128 +503,171 @@ k_prepare_cert(const float* __restrict__ lo_fwd, const float* __restrict__ lo_bw
           norm_box(m.z, m.w, g.ht, b.z, b.w);
           tab[d][q] = b;
           const float wxb = b.y - b.x, wyb = b.w - b.z;
-          if (!(wxb * wxb + wyb * wyb <= g.a2)) atomicAdd(&wide_boxes, 1);   // cannot certify anything
+          if (!(wxb * wxb + wyb * wyb <= g.a2)) {                            // cannot certify anything
+            if (j <= c64) atomicAdd(&wide_boxes[0], 1);
+            if (j >= c64) atomicAdd(&wide_boxes[1], 1);
+          }
         }
       }
     }
     __syncthreads();
     // most boxes beyond the tolerance: the generic per-pixel fallback would dominate; the staged kernel is cheaper
-    if (force != 1) certify = certify && 4 * wide_boxes <= 2 * urows * ucols;
-    certify = uniform(certify);
-    if (!certify && t < 2 && ty0 + t * TY < g.Hf)          // both staged tiles under this one
-      mask_fwd[(size_t)n * HW + (size_t)(ty0 + t * TY) * g.Wf + tx0] = TILE_MARK;
+    // The hand-over is decided per 64-column half (one column of two staged tiles): a motion boundary through one half
+    // must not send the other half's pixels to the staged kernel, nor its own to the generic per-pixel path.
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const int cols = hh ? ucols - c64 : min(c64 + 1, ucols);
+      cert_h[hh] = uniform(certify && (force == 1 || 4 * wide_boxes[hh] <= 2 * urows * cols));
+    }
+    certify = cert_h[0] || cert_h[1];
+    if (t < 4 && !cert_h[t & 1] && ty0 + (t >> 1) * TY < g.Hf && tx0 + (t & 1) * TX < g.Wf)   // the staged tiles of that half
+      mask_fwd[(size_t)n * HW + (size_t)(ty0 + (t >> 1) * TY) * g.Wf + tx0 + (t & 1) * TX] = TILE_MARK;
   }
   const float a2c = g.a2 * (1.f - 2.f * BOX_SLOP);
-  // ---- the pixels: lane = column, each wave walks ROWS_C rows; separable up-sampling as in the staged kernel
-  const int x = tx0 + lane;
-  const bool act = x < g.Wf;
-  const AxF ax = axf(min(x, g.Wf - 1), g.sx);
-  const int cxi = ax.i0 - wx0;
-  const float c0x = div_c(2.f * (float)x, g.wd) - 1.f;
-  float4 t0 = make_float4(0.f, 0.f, 0.f, 0.f), t1 = t0, bxf = t0, bxb = t0;   // bxf: bwd-flow box for fwd pixels
+  // ---- the pixels: a lane owns the columns x0, x0 + 1 (x0 even), each wave walks ROWS_C rows; separable up-sampling as in
+  // the staged kernel.  Two columns per lane because of the masks: one byte per lane is a 64-B piece of a 128-B line per
+  // wave instruction, and pieces of lines are what the memory side handles worst (tools/ubench/store_pattern.hip: the
+  // same bytes stored as 4 B + 1 B per lane take 1.12 ms, as 8 B + 2 B per lane 0.76 ms); two bytes per lane are whole
+  // lines, the flows leave as 8 B per lane, and a tile's tables serve twice the pixels.
+  const int x0 = tx0 + 2 * lane;
+  const bool act = x0 < g.Wf;                                  // Wf is even: both columns or none
+  const bool cert_l = lane < 32 ? cert_h[0] : cert_h[1];       // this lane's half has its masks decided here
+  AxF ax[2];
+  int cxi[2];
+  float c0x[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    ax[u] = axf(min(x0 + u, g.Wf - 1), g.sx);
+    cxi[u] = ax[u].i0 - wx0;
+    c0x[u] = div_c(2.f * (float)(x0 + u), g.wd) - 1.f;
+  }
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 t0[2] = {z4, z4}, t1[2] = {z4, z4}, bxf[2] = {z4, z4}, bxb[2] = {z4, z4};   // bxf: bwd-flow box for fwd pixels
   int have = -2, badf = 0, badb = 0;                           // bad counts are wave-uniform
-  unsigned undecided = 0;                                      // bit 2*rr + d: inside the frame but not certified
-  bool cellok[2] = {false, false};                             // both directions certified for the current run of rows
-  bool allok = false;                                          // ... in every lane of the wave
-  float* of = flow_fwd + (size_t)n * 2 * HW + x;
-  float* ob = flow_bwd + (size_t)n * 2 * HW + x;
+  unsigned long long undecided = 0;                            // bit 4*rr + 2*u + d: inside the frame but not certified
+  bool cellok[2][2] = {{false, false}, {false, false}};        // [column][direction] certified for the current run of rows
+  bool allok = false;                                          // ... everything, in every lane of the wave
+  float* of = flow_fwd + (size_t)n * 2 * HW + x0;
+  float* ob = flow_bwd + (size_t)n * 2 * HW + x0;
+  uint8_t* mf = mask_fwd + (size_t)n * HW + x0;
+  uint8_t* mb = mask_bwd + (size_t)n * HW + x0;
   const int yw = ty0 + wave * ROWS_C;
   for (int rr = 0; rr < ROWS_C; ++rr) {
     const int y = yw + rr;
     if (y >= g.Hf) break;                                      // wave-uniform
     const AxF ay = axf(y, g.sy);
     if (ay.i0 != have) {
-      const float4* cell = cw + (MARG + ay.i0 - wy0) * WW + MARG + cxi;
-      if (ay.i0 == have + 1) {
-        t0 = t1;
-      } else {
-        const float4 a = cell[0], b = cell[1];
-        t0 = make_float4(up8_row(a.x, b.x, ax.l0, ax.l1), up8_row(a.y, b.y, ax.l0, ax.l1),
-                         up8_row(a.z, b.z, ax.l0, ax.l1), up8_row(a.w, b.w, ax.l0, ax.l1));
-      }
-      const float4 c = cell[WW], d = cell[WW + 1];
-      t1 = make_float4(up8_row(c.x, d.x, ax.l0, ax.l1), up8_row(c.y, d.y, ax.l0, ax.l1),
-                       up8_row(c.z, d.z, ax.l0, ax.l1), up8_row(c.w, d.w, ax.l0, ax.l1));
-      if (certify) {
-        const int ci = (ay.i0 - wy0) * W0_W + cxi;
-        bxf = tab[0][ci]; bxb = tab[1][ci];
-        // Certificate for ALL rows of this lane that share the cell row (at most 9): between the two x-interpolated
-        // source rows the column pass is a convex combination, so the lane's own flow stays in [min(t0,t1), max(t0,t1)]
-        // per channel; with the box of the opposite flow that bounds |fn + b'| for the whole run of rows, and the first /
-        // last possible row bound the position.  Where it holds (smooth flow: almost everywhere) the rows below cost the
-        // up-sampling and the stores only.
-        const float cya = div_c(2.f * (float)y, g.ht) - 1.f, cyb = div_c(2.f * (float)min(y + 9, g.Hf - 1), g.ht) - 1.f;
+      const float cya = div_c(2.f * (float)y, g.ht) - 1.f, cyb = div_c(2.f * (float)min(y + 9, g.Hf - 1), g.ht) - 1.f;
+      bool ok_all = true;
 #pragma unroll
-        for (int d = 0; d < 2; ++d) {
-          const float ax_ = d ? t0.z : t0.x, bx_ = d ? t1.z : t1.x, ay_ = d ? t0.w : t0.y, by_ = d ? t1.w : t1.y;
-          float fLx, fUx, fLy, fUy;
-          norm_box(fminf(ax_, bx_), fmaxf(ax_, bx_), g.wd, fLx, fUx);
-          norm_box(fminf(ay_, by_), fmaxf(ay_, by_), g.ht, fLy, fUy);
-          const float4 bx = d ? bxb : bxf;
-          const bool in_all = (c0x + fLx > -1.f) && (c0x + fUx < 1.f) && (cya + fLy > -1.f) && (cyb + fUy < 1.f);
-          const float mx = fmaxf(fabsf(fLx + bx.x), fabsf(fUx + bx.y));
-          const float my = fmaxf(fabsf(fLy + bx.z), fabsf(fUy + bx.w));
-          cellok[d] = in_all && (__builtin_fmaf(mx, mx, my * my) <= a2c);      // false for NaN
+      for (int u = 0; u < 2; ++u) {
+        const float4* cell = cw + (MARG + ay.i0 - wy0) * WW + MARG + cxi[u];
+        const AxF& a_ = ax[u];
+        if (ay.i0 == have + 1) {
+          t0[u] = t1[u];
+        } else {
+          const float4 a = cell[0], b = cell[1];
+          t0[u] = make_float4(up8_row(a.x, b.x, a_.l0, a_.l1), up8_row(a.y, b.y, a_.l0, a_.l1),
+                              up8_row(a.z, b.z, a_.l0, a_.l1), up8_row(a.w, b.w, a_.l0, a_.l1));
         }
-        allok = __all(cellok[0] && cellok[1]) != 0;            // the rows of a wave change cell rows together
+        const float4 c = cell[WW], d = cell[WW + 1];
+        t1[u] = make_float4(up8_row(c.x, d.x, a_.l0, a_.l1), up8_row(c.y, d.y, a_.l0, a_.l1),
+                            up8_row(c.z, d.z, a_.l0, a_.l1), up8_row(c.w, d.w, a_.l0, a_.l1));
+        if (cert_l) {
+          const int ci = (ay.i0 - wy0) * W0_W + cxi[u];
+          bxf[u] = tab[0][ci]; bxb[u] = tab[1][ci];
+          // Certificate for ALL rows of this column that share the cell row (at most 9): between the two x-interpolated
+          // source rows the column pass is a convex combination, so the column's own flow stays in [min(t0,t1), max(t0,t1)]
+          // per channel; with the box of the opposite flow that bounds |fn + b'| for the whole run of rows, and the first /
+          // last possible row bound the position.  Where it holds (smooth flow: almost everywhere) the rows below cost the
+          // up-sampling and the stores only.
+#pragma unroll
+          for (int d2 = 0; d2 < 2; ++d2) {
+            const float ax_ = d2 ? t0[u].z : t0[u].x, bx_ = d2 ? t1[u].z : t1[u].x;
+            const float ay_ = d2 ? t0[u].w : t0[u].y, by_ = d2 ? t1[u].w : t1[u].y;
+            float fLx, fUx, fLy, fUy;
+            norm_box(fminf(ax_, bx_), fmaxf(ax_, bx_), g.wd, fLx, fUx);
+            norm_box(fminf(ay_, by_), fmaxf(ay_, by_), g.ht, fLy, fUy);
+            const float4 bx = d2 ? bxb[u] : bxf[u];
+            const bool in_all = (c0x[u] + fLx > -1.f) && (c0x[u] + fUx < 1.f) && (cya + fLy > -1.f) && (cyb + fUy < 1.f);
+            const float mx = fmaxf(fabsf(fLx + bx.x), fabsf(fUx + bx.y));
+            const float my = fmaxf(fabsf(fLy + bx.z), fabsf(fUy + bx.w));
+            cellok[u][d2] = in_all && (__builtin_fmaf(mx, mx, my * my) <= a2c);    // false for NaN
+            ok_all = ok_all && cellok[u][d2];
+          }
+        }
       }
+      if (certify) allok = __all(ok_all || !cert_l) != 0;      // the rows of a wave change cell rows together
       have = ay.i0;
     }
-    if (allok) {                                               // wave-uniform: flows and two constant mask bytes
+    const size_t q = (size_t)y * g.Wf;
+    if (allok) {                                               // wave-uniform: flows and two constant mask words
       if (act) {
-        const size_t q = (size_t)y * g.Wf;
-        of[q] = 8.f * up8_col(t0.x, t1.x, ay.l0, ay.l1); of[HW + q] = 8.f * up8_col(t0.y, t1.y, ay.l0, ay.l1);
-        ob[q] = 8.f * up8_col(t0.z, t1.z, ay.l0, ay.l1); ob[HW + q] = 8.f * up8_col(t0.w, t1.w, ay.l0, ay.l1);
-        mask_fwd[(size_t)n * HW + q + x] = 1;
-        mask_bwd[(size_t)n * HW + q + x] = 1;
+        *reinterpret_cast<float2*>(of + q) = make_float2(8.f * up8_col(t0[0].x, t1[0].x, ay.l0, ay.l1), 8.f * up8_col(t0[1].x, t1[1].x, ay.l0, ay.l1));
+        *reinterpret_cast<float2*>(of + HW + q) = make_float2(8.f * up8_col(t0[0].y, t1[0].y, ay.l0, ay.l1), 8.f * up8_col(t0[1].y, t1[1].y, ay.l0, ay.l1));
+        *reinterpret_cast<float2*>(ob + q) = make_float2(8.f * up8_col(t0[0].z, t1[0].z, ay.l0, ay.l1), 8.f * up8_col(t0[1].z, t1[1].z, ay.l0, ay.l1));
+        *reinterpret_cast<float2*>(ob + HW + q) = make_float2(8.f * up8_col(t0[0].w, t1[0].w, ay.l0, ay.l1), 8.f * up8_col(t0[1].w, t1[1].w, ay.l0, ay.l1));
+        if (cert_l) {
+          *reinterpret_cast<uint16_t*>(mf + q) = 0x0101;
+          *reinterpret_cast<uint16_t*>(mb + q) = 0x0101;
+        }
       }
       continue;
     }
     // 16 * (interpolated value) = 2 * upflow8 value; both scalings are exact
-    const float fx16 = 16.f * up8_col(t0.x, t1.x, ay.l0, ay.l1), fy16 = 16.f * up8_col(t0.y, t1.y, ay.l0, ay.l1);
-    const float bx16 = 16.f * up8_col(t0.z, t1.z, ay.l0, ay.l1), by16 = 16.f * up8_col(t0.w, t1.w, ay.l0, ay.l1);
-    const size_t q = (size_t)y * g.Wf;
-    if (act) {
-      of[q] = 0.5f * fx16; of[HW + q] = 0.5f * fy16;
-      ob[q] = 0.5f * bx16; ob[HW + q] = 0.5f * by16;
+    float fx16[2], fy16[2], bx16[2], by16[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      fx16[u] = 16.f * up8_col(t0[u].x, t1[u].x, ay.l0, ay.l1); fy16[u] = 16.f * up8_col(t0[u].y, t1[u].y, ay.l0, ay.l1);
+      bx16[u] = 16.f * up8_col(t0[u].z, t1[u].z, ay.l0, ay.l1); by16[u] = 16.f * up8_col(t0[u].w, t1[u].w, ay.l0, ay.l1);
     }
-    if (!certify) continue;                                    // block-uniform
-    bool ok[2] = {true, true};
-    if (!(cellok[0] && cellok[1])) {                           // the per-pixel certificate, where the run of rows failed
-      const float c0y = div_c(2.f * (float)y, g.ht) - 1.f;
-      const float fn[2][2] = {{div_c(fx16, g.wd), div_c(fy16, g.ht)}, {div_c(bx16, g.wd), div_c(by16, g.ht)}};
+    if (act) {
+      *reinterpret_cast<float2*>(of + q) = make_float2(0.5f * fx16[0], 0.5f * fx16[1]);
+      *reinterpret_cast<float2*>(of + HW + q) = make_float2(0.5f * fy16[0], 0.5f * fy16[1]);
+      *reinterpret_cast<float2*>(ob + q) = make_float2(0.5f * bx16[0], 0.5f * bx16[1]);
+      *reinterpret_cast<float2*>(ob + HW + q) = make_float2(0.5f * by16[0], 0.5f * by16[1]);
+    }
+    if (!certify) continue;                                    // block-uniform; below, a lane of a handed-over half
+                                                               // (!cert_l) takes part in the ballots and contributes nothing
+    bool ok[2][2] = {{true, true}, {true, true}};              // [column][direction]
+    const float c0y = div_c(2.f * (float)y, g.ht) - 1.f;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if ((cellok[u][0] && cellok[u][1]) || !cert_l) continue; // the per-pixel certificate, where the run of rows failed
+      const float fn[2][2] = {{div_c(fx16[u], g.wd), div_c(fy16[u], g.ht)}, {div_c(bx16[u], g.wd), div_c(by16[u], g.ht)}};
 #pragma unroll
       for (int d = 0; d < 2; ++d) {
-        if (cellok[d]) continue;
-        const float4 bx = d ? bxb : bxf;
-        const float c1x = c0x + fn[d][0], c1y = c0y + fn[d][1];
+        if (cellok[u][d]) continue;
+        const float4 bx = d ? bxb[u] : bxf[u];
+        const float c1x = c0x[u] + fn[d][0], c1y = c0y + fn[d][1];
         const bool inside = (fabsf(c1x) < 1.f) && (fabsf(c1y) < 1.f);
         const float mx = fmaxf(fabsf(fn[d][0] + bx.x), fabsf(fn[d][0] + bx.y));
         const float my = fmaxf(fabsf(fn[d][1] + bx.z), fabsf(fn[d][1] + bx.w));
         const bool sure = __builtin_fmaf(mx, mx, my * my) <= a2c;
-        ok[d] = inside && sure;
-        if (inside && !sure) undecided |= 1u << (2 * rr + d);   // settled exactly after the loop
+        ok[u][d] = inside && sure;
+        if (inside && !sure) undecided |= 1ull << (4 * rr + 2 * u + d);   // settled exactly after the loop
       }
     }
-    if (act) {
-      mask_fwd[(size_t)n * HW + q + x] = ok[0] ? 1 : 0;
-      mask_bwd[(size_t)n * HW + q + x] = ok[1] ? 1 : 0;
+    const bool mine = act && cert_l;
+    if (mine) {
+      *reinterpret_cast<uint16_t*>(mf + q) = (uint16_t)((ok[0][0] ? 1 : 0) | (ok[1][0] ? 0x100 : 0));
+      *reinterpret_cast<uint16_t*>(mb + q) = (uint16_t)((ok[0][1] ? 1 : 0) | (ok[1][1] ? 0x100 : 0));
     }
-    badf += __popcll(__ballot(act && !ok[0]));
-    badb += __popcll(__ballot(act && !ok[1]));
+    badf += __popcll(__ballot(mine && !ok[0][0])) + __popcll(__ballot(mine && !ok[1][0]));
+    badb += __popcll(__ballot(mine && !ok[0][1])) + __popcll(__ballot(mine && !ok[1][1]));
   }
   // Pixels the certificate could not settle (rare in a tile that was not handed over): the exact generic evaluation, kept
   // out of the loop above so that the call does not dictate its register allocation.  (Handing such tiles to the staged
-  // kernel instead makes this kernel leaner - 46 VGPRs - but re-does whole tiles for a few pixels: 0.96 vs 0.88 ms.)
+  // kernel instead makes this kernel leaner but re-does whole tiles for a few pixels: 0.96 vs 0.88 ms.)
   if (!act) undecided = 0;
   while (__any(undecided != 0)) {
     bool fixed_f = false, fixed_b = false;
     if (undecided) {
-      const int bit = __builtin_ctz(undecided);
+      const int bit = __builtin_ctzll(undecided);
       undecided &= undecided - 1;
-      const int d = bit & 1, y = yw + (bit >> 1);
-      if (fbc_generic(d ? gb : gf, d ? gf : gb, g.h, g.w, y, x, g.alpha1, g.a2)) {
-        (d ? mask_bwd : mask_fwd)[(size_t)n * HW + (size_t)y * g.Wf + x] = 1;
+      const int d = bit & 1, u = (bit >> 1) & 1, y = yw + (bit >> 2);
+      if (fbc_generic(d ? gb : gf, d ? gf : gb, g.h, g.w, y, x0 + u, g.alpha1, g.a2)) {
+        (d ? mb : mf)[(size_t)y * g.Wf + u] = 1;
         fixed_f = d == 0; fixed_b = d == 1;
       }
     }
@@ -1330,7 +1382,7 @@ int run_flow_prepare(const float* lo_fwd, const float* lo_bwd, float* flow_fwd, 
       int force = !path ? 0 : !strcmp(path, "certified") ? 1 : !strcmp(path, "staged") ? 2 : 0;
       if (!(alpha1 >= 0.f)) force = 2;      // the certificate needs eps >= a2, i.e. alpha1 >= 0
       const Up8Geom g = make_geom(h, w, Hf, Wf, alpha1, a2);
-      hipLaunchKernelGGL(k_prepare_cert, dim3(grid.x, (Hf + TYC - 1) / TYC, N), dim3(NT_C), 0, st, lo_fwd, lo_bwd, flow_fwd, flow_bwd,
+      hipLaunchKernelGGL(k_prepare_cert, dim3((Wf + TXC - 1) / TXC, (Hf + TYC - 1) / TYC, N), dim3(NT_C), 0, st, lo_fwd, lo_bwd, flow_fwd, flow_bwd,
                          mask_fwd, mask_bwd, invalid, N, g, force);
       if (mask_fwd) {
         CHECKED("k_prepare_cert");
