@@ -377,6 +377,30 @@ def test_full_size_vs_oracle(dev, shape, generic):
         close(a, b)
 
 
+@pytest.mark.parametrize("N,C,H,W,p", [
+    (3, 256, 10, 10, 2.0),     # 6 (direction, sample) pairs: the XCD placement's remainder branch; P = 100: k tail of 4, tiles 4 + 3
+    (5, 128, 12, 12, 2.0),     # P = 144 = 9 whole tiles dealt 3 + 3 + 3; two row tiles per wave
+    (9, 64, 9, 12, 1.0),       # P = 108: a 12-column last tile, k tail of 12; one row tile per wave; p = 1
+    (8, 256, 8, 8, 2.0),       # P = 64 exactly (one strip, one Gram tile); too large for the single-launch kernel's LDS
+    (2, 256, 16, 17, 2.0),     # P = 272 > 256: five strips, five Gram tiles per side incl. a 16-column one
+    (2, 128, 10, 12, 0.5),     # p < 1: A = (max(S, c) + 1e-6)^p, dA/dS up to 500 - gradients to 2e-3 (both paths re-associate S)
+    (1, 256, 14, 14, 2.0),     # a single sample
+])
+def test_tiled_path_shapes_vs_staged(dev, N, C, H, W, p):
+    """The tiled path's indexing away from the 14 x 14 / N = 64 case it is tuned for: channel counts (row tiles per wave),
+    grids whose P is no multiple of 16 or 64 (partial column tiles, partial last k slab fed from the zero chunk, clamped
+    duplicate columns), and batches whose number of (direction, sample) pairs is no multiple of eight (placement remainder).
+    Against the staged path on the device (itself held to the oracle above): pos_num exact, loss 1e-5, pred 2e-6, grads 1e-4."""
+    P = _random_problem(dev, N, C, H, W, 96, 128, seed=100 + N + H)
+    ot, gt = _run_hip(dev, P, p=p, generic=False, want_pred=True)
+    og, gg = _run_hip(dev, P, p=p, generic=True, want_pred=True)
+    assert torch.equal(ot[1], og[1]) and torch.equal(ot[2], og[2]) and ot[1].sum().item() > 0
+    assert abs(ot[0].item() - og[0].item()) <= 1e-5 * max(1.0, abs(og[0].item()))
+    assert (ot[4] - og[4]).abs().max().item() <= 2e-6
+    for a, b in zip(gt, gg):
+        close(a, b, rel=1e-4 if p >= 1.0 else 2e-3)
+
+
 def test_tiled_equals_staged_and_properties(dev):
     """14 x 14 grid: the tiled path against the staged path on the device, plus the size-independent properties
     (all-false mask -> zero loss and gradients, linearity in the upstream gradient, forward-only call)."""
