@@ -1,20 +1,24 @@
 // Tiled multi-launch PPM -> flow-matched pixel loss -> backward for grids too large for the single-launch kernel
 // (P = H*W > 64, e.g. the 14 x 14 grid of 448^2 crops: one [256][196] fp32 tile is 200 KB, one P x P matrix 154 KB, against
-// 160 KB of LDS).  Seven launches instead of the ~22 of ppm_generic.hip; the P x P matrices live in the caller's
+// 160 KB of LDS).  Five launches instead of the ~22 of ppm_generic.hip; the P x P matrices live in the caller's
 // workspace (L2 / Infinity Cache resident at these sizes), everything between two matrix products is an epilogue:
 //
-//   k_tl_prep     sample points (flow-displaced bin centres), positive-pair BIT rows, counts          PixPro.py:132-223
-//   k_tl_rnorms   1 / max(||.||, 1e-12) of the columns of x, v, k                                      :344,348,403
+//   k_tl_pre      1 / max(||.||, 1e-12) of the columns of x, v, k (PixPro.py:344,348,403)  |  sample points (flow-displaced
+//                 bin centres), positive-pair BIT rows, counts (:132-223) - independent work-groups of one launch
 //   k_tl_gram<0>  S = x^T x on 64 x 64 tiles (K = C), epilogue: normalise, clamp/pow -> A, dA/dS       :354-358
-//   k_tl_strip<0> per 64-column strip, all C rows in one work-group: Y = v^ A, column norms, Y^ (:361,380);
+//   k_tl_strip<0> per strip of columns, all C rows in one work-group: Y = v^ A, column norms, Y^ (:361,380);
 //                 G = k^ M^T with M expanded from the bit rows (:239); <Y^,G> -> loss partials (:241); dY
-//   k_tl_gram<1>  dA = dY^T v^ on tile PAIRS (i,j),(j,i), epilogue: dS = dA o D, dSs = dS + dS^T
-//   k_tl_strip<1|2>  dV^ = dY A -> dv ; dX^ = x^ dSs -> dx   (one launch, blockIdx.z selects)
-//   k_tl_finish   loss_n, loss                                                                          :241,247
+//   k_tl_gram<1>  dA = dY^T v^ on tile PAIRS (i,j),(j,i) in one sweep, epilogue: dS = dA o D, dSs = dS + dS^T; its first
+//                 work-group also reduces the loss (:241,247)
+//   k_tl_strip<1> dV^ = dY A -> dv ; dX^ = x^ dSs -> dx   (one launch, the item index selects)
+//   (k_tl_finish  loss_n, loss: a launch of its own only in forward-only calls)
 //
-// All products run on the exact-fp32 MFMA v_mfma_f32_16x16x4_f32 with operands staged through LDS in 16-deep slabs
-// (next slab requested into registers before the MFMAs of the current one).  Same math and tolerances as the other two
-// paths; the bit-exact part (points, threshold, mask) uses the same helpers as ppm_fused.hip.
+// All products run on the exact-fp32 MFMA v_mfma_f32_16x16x4_f32.  Round 3: operands arrive by LDS-DMA
+// (global_load_lds_dwordx4) in rings of three slabs with one barrier per slab; both operands of the strip products are
+// k-contiguous (the P x P matrices are symmetric up to a column scaling the producer applies) and read as ds_read_b128
+// fragments; the 16-column tiles are dealt evenly to the strips; every epilogue moves its global traffic in 256-B rows
+// through LDS; the work-groups of one (direction, sample) are placed on one XCD.  Same math and tolerances as the other
+// two paths; the bit-exact part (points, threshold, mask) uses the same helpers as ppm_fused.hip.
 #include "common.h"
 
 namespace pixpro {
@@ -25,11 +29,10 @@ namespace {
                                  // Gram kernels: 8 no epilogue stores, 16 no MFMA, 32 no copies after the first two slabs
 #endif
 constexpr int TB = 256;          // threads per work-group: 4 waves
-constexpr int TSB = 80;          // LDS row stride of a 64-wide operand slab (conflict-free MFMA operand reads)
 
 struct TlWs {                    // workspace carve (floats unless noted)
   float *rx, *rv, *rk;           // [B][P] reciprocal column norms
-  float *cnt, *lpart;            // [B], [B][strips]
+  float *cnt, *lpart;            // [B][PREP_S] partial counts, [B][strips]
   float *A, *Dm, *dSs, *Av;      // [B][P][P]; Av[n][k] = rv[k] A[n][k], dSs[n][k] = rx[k] (dS + dS^T)[n][k]: the scales of
                                  // the strip products sit on the COLUMNS, row n of the stored matrix is operand column n
   float *dY;                     // [B][C][P]
@@ -42,7 +45,7 @@ inline size_t al256(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
 size_t tl_bytes(const pixpro_problem& pb) {
   const size_t B = (size_t)pb.N * pb.ndir, P = (size_t)pb.H * pb.W, R = (size_t)pb.C * P, Q = P * P, W64 = (P + 63) / 64;
   const size_t strips = (P + 63) / 64;
-  return 3 * al256(B * P * 4) + al256(B * 4) + al256(B * strips * 4) + 4 * al256(B * Q * 4) + al256(B * R * 4) +
+  return 3 * al256(B * P * 4) + al256(B * 4 * 4) + al256(B * strips * 4) + 4 * al256(B * Q * 4) + al256(B * R * 4) +
          al256(B * P * W64 * 8) + 256 + 4096;
 }
 
@@ -53,7 +56,7 @@ TlWs tl_carve(void* ws, const pixpro_problem& pb) {
   auto take = [&](size_t bytes) { char* r = p; p += al256(bytes); return r; };
   TlWs w;
   w.rx = (float*)take(B * P * 4); w.rv = (float*)take(B * P * 4); w.rk = (float*)take(B * P * 4);
-  w.cnt = (float*)take(B * 4); w.lpart = (float*)take(B * strips * 4);
+  w.cnt = (float*)take(B * 4 * 4); w.lpart = (float*)take(B * strips * 4);   // 4 = PREP_S
   w.A = (float*)take(B * Q * 4); w.Dm = (float*)take(B * Q * 4); w.dSs = (float*)take(B * Q * 4);
   w.Av = (float*)take(B * Q * 4);
   w.dY = (float*)take(B * R * 4);
@@ -82,17 +85,76 @@ __device__ __forceinline__ float tl_dist_threshold(float diag, float r, int lane
   return __uint_as_float(hi > 0x7f800000LL ? 0x7f800000u : (unsigned)hi);
 }
 
-// ---- k_tl_prep: PREP_S work-groups per (direction, sample), each takes every PREP_S-th group of 4 rows ------------------
 constexpr int TL_MAXP = 1024, PREP_S = 4;
-__global__ void __launch_bounds__(TB) k_tl_prep(pixpro_problem pb, Dirs D, unsigned long long* __restrict__ bits,
-                                                float* __restrict__ cnt) {
+// positive pairs of (direction, sample) b: the PREP_S partial counts of k_tl_pre (integers below 2^24: exact in any order)
+__device__ __forceinline__ float cnt_of(const float* __restrict__ cnt, int b) {
+  float c = 0.f;
+#pragma unroll
+  for (int k = 0; k < PREP_S; ++k) c += cnt[b * PREP_S + k];
+  return c;
+}
+
+// ---- k_tl_pre: ONE launch for what depends on the inputs alone (round 2: two launches, 19 + 15 us; the norms are a
+// stream, the sample points a latency chain of flow taps - they overlap well) ----------------------------------------------
+//   work-groups [0, 6 B):        1 / max(||.||, 1e-12) of the columns of x, v, k: one work-group per (pair, tensor, column
+//                                half) - 16 B per lane along the rows (k_tl_rnorms read 4 B per lane in 64-column strips,
+//                                a quarter of them holding 4 of 196 columns), three equal streams per CU
+//   work-groups [6 B, 6 B + PREP_S B):  sample points (flow-displaced bin centres), positive-pair BIT rows, counts; every
+//                                work-group of a pair takes every PREP_S-th group of 4 rows
+__global__ void __launch_bounds__(TB) k_tl_pre(pixpro_problem pb, Dirs D, TlWs w) {
   __shared__ float qx[TL_MAXP], qy[TL_MAXP], kx[TL_MAXP], ky[TL_MAXP];
   __shared__ int valid[TL_MAXP];
   __shared__ float sT;
   __shared__ int wcnt[TB / 64];
-  const int b = blockIdx.x, d = b / pb.N, n = b % pb.N, P = pb.H * pb.W, W64 = (P + 63) / 64;
+  const int B = pb.N * pb.ndir, P = pb.H * pb.W, W64 = (P + 63) / 64, C = pb.C;
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
-  const int row0 = 4 * blockIdx.y + wave, rstep = 4 * PREP_S;        // this wave's rows: row0, row0 + rstep, ...
+  if ((int)blockIdx.x < 6 * B) {
+    // ---- column norms
+    const int q = blockIdx.x, half = q & 1, which = (q >> 1) % 3, b = q / 6;
+    if (q == 0 && t < 16) w.zero[t] = 0.f;
+    const pixpro_dir& dd = D.d[b / pb.N];
+    const float* s = (which == 0 ? dd.x : which == 1 ? dd.v : dd.k) + (size_t)(b % pb.N) * C * P;
+    float* o = (which == 0 ? w.rx : which == 1 ? w.rv : w.rk) + (size_t)b * P;
+    const int f4 = P / 4, h0 = (f4 + 1) / 2, c0 = half ? h0 : 0, fw = half ? f4 - h0 : h0;   // this half's float4 columns
+    if (fw == 0) return;
+    if (which == 2 && !pb.normalize_k) {
+      for (int j = t; j < 4 * fw; j += TB) o[4 * c0 + j] = 1.f;
+      return;
+    }
+    const int rp = TB / fw, r = t / fw, c4 = t - r * fw;             // rows per pass; this thread's row and column
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < rp) {
+      const float* col = s + 4 * (c0 + c4);
+      int row = r;
+      for (; row + 3 * rp < C; row += 4 * rp) {                      // four rows in flight
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(col + (size_t)(row + u * rp) * P);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          a.x = __builtin_fmaf(v[u].x, v[u].x, a.x); a.y = __builtin_fmaf(v[u].y, v[u].y, a.y);
+          a.z = __builtin_fmaf(v[u].z, v[u].z, a.z); a.w = __builtin_fmaf(v[u].w, v[u].w, a.w);
+        }
+      }
+      for (; row < C; row += rp) {
+        const float4 v = *reinterpret_cast<const float4*>(col + (size_t)row * P);
+        a.x = __builtin_fmaf(v.x, v.x, a.x); a.y = __builtin_fmaf(v.y, v.y, a.y);
+        a.z = __builtin_fmaf(v.z, v.z, a.z); a.w = __builtin_fmaf(v.w, v.w, a.w);
+      }
+      *reinterpret_cast<float4*>(&qx[4 * t]) = a;                    // qx as scratch: [row group][column] partial sums
+    }
+    __syncthreads();
+    for (int j = t; j < 4 * fw; j += TB) {
+      float sum = 0.f;
+      for (int k = 0; k < rp; ++k) sum += qx[4 * fw * k + j];        // fixed order
+      o[4 * c0 + j] = 1.f / fmaxf(sqrtf(sum), 1e-12f);
+    }
+    return;
+  }
+  // ---- sample points, bit rows, counts
+  const int pq = blockIdx.x - 6 * B, b = pq / PREP_S, part = pq - b * PREP_S;
+  const int d = b / pb.N, n = b % pb.N;
+  const int row0 = 4 * part + wave, rstep = 4 * PREP_S;              // this wave's rows: row0, row0 + rstep, ...
   const pixpro_dir& dd = D.d[d];
   int Ho, Wo;
   frame_size(pb, dd, Ho, Wo);
@@ -102,7 +164,7 @@ __global__ void __launch_bounds__(TB) k_tl_prep(pixpro_problem pb, Dirs D, unsig
   for (int i = t; i < P; i += TB) {
     const int row = i / pb.W, col = i % pb.W;
     kx[i] = centre_x(ck, col, wo1); ky[i] = centre_y(ck, row, ho1);
-    if ((i >> 2) % PREP_S != (int)blockIdx.y) continue;              // q points of the rows this work-group owns
+    if ((i >> 2) % PREP_S != part) continue;                         // q points of the rows this work-group owns
     float x = centre_x(cq, col, wo1), y = centre_y(cq, row, ho1);
     bool v = true;
     if (dd.lo_own) {            // lazy flow mode (common.h)
@@ -129,15 +191,15 @@ __global__ void __launch_bounds__(TB) k_tl_prep(pixpro_problem pb, Dirs D, unsig
   for (int i = row0; i < P; i += rstep) {
     const float xi = qx[i], yi = qy[i];
     const bool vi = valid[i] != 0;
-    for (int w = 0; w < W64; ++w) {
-      const int j = 64 * w + lane;
+    for (int wd = 0; wd < W64; ++wd) {
+      const int j = 64 * wd + lane;
       bool pred = false;
       if (j < P) {
         const float dx = xi - kx[j], dy = yi - ky[j];
         pred = (dx * dx + dy * dy < T) && vi;
       }
       const unsigned long long m = __ballot(pred);
-      if (lane == 0) bits[((size_t)b * P + i) * W64 + w] = m;
+      if (lane == 0) w.bits[((size_t)b * P + i) * W64 + wd] = m;
       c += __popcll(m);
     }
   }
@@ -145,37 +207,9 @@ __global__ void __launch_bounds__(TB) k_tl_prep(pixpro_problem pb, Dirs D, unsig
   __syncthreads();
   if (t == 0) {
     int tot = 0;
-    for (int w = 0; w < TB / 64; ++w) tot += wcnt[w];
-    if (tot) atomicAdd(&cnt[b], (float)tot);      // integers below 2^24: exact in any order (cnt is zeroed by the host side)
+    for (int k = 0; k < TB / 64; ++k) tot += wcnt[k];
+    w.cnt[b * PREP_S + part] = (float)tot;
   }
-}
-
-// ---- k_tl_rnorms: grid (ceil(P/64), B, 3) -----------------------------------------------------------------------------
-__global__ void __launch_bounds__(TB) k_tl_rnorms(Dirs D, float* __restrict__ rx, float* __restrict__ rv,
-                                                  float* __restrict__ rk, float* __restrict__ cnt, float* __restrict__ zero,
-                                                  int N, int C, int P, int normalize_k) {
-  __shared__ float red[4][64];
-  const int b = blockIdx.y, which = blockIdx.z, tx = threadIdx.x & 63, ty = threadIdx.x >> 6, j = blockIdx.x * 64 + tx;
-  if (blockIdx.x == 0 && which == 0 && threadIdx.x == 0) cnt[b] = 0.f;   // k_tl_prep (next launch) accumulates into it
-  if (blockIdx.x == 0 && blockIdx.y == 0 && which == 0 && threadIdx.x < 16) zero[threadIdx.x] = 0.f;
-  const pixpro_dir& dd = D.d[b / N];
-  const float* s = (which == 0 ? dd.x : which == 1 ? dd.v : dd.k) + (size_t)(b % N) * C * P;
-  float* o = (which == 0 ? rx : which == 1 ? rv : rk) + (size_t)b * P;
-  if (which == 2 && !normalize_k) {
-    if (ty == 0 && j < P) o[j] = 1.f;
-    return;
-  }
-  float a0 = 0.f, a1 = 0.f;
-  if (j < P) {
-    for (int c = ty; c < C; c += 8) {
-      const float t0 = s[(size_t)c * P + j], t1 = (c + 4 < C) ? s[(size_t)(c + 4) * P + j] : 0.f;
-      a0 = __builtin_fmaf(t0, t0, a0);
-      a1 = __builtin_fmaf(t1, t1, a1);
-    }
-  }
-  red[ty][tx] = a0 + a1;
-  __syncthreads();
-  if (ty == 0 && j < P) o[j] = 1.f / fmaxf(sqrtf(red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx]), 1e-12f);
 }
 
 // ---- XCD-aware placement ----------------------------------------------------------------------------------------------
@@ -218,16 +252,22 @@ __device__ __forceinline__ void lds_barrier() {          // LDS traffic of this 
 
 // ---- P x P products over K = C on 64 x 64 tiles --------------------------------------------------------------------------
 // NP 64 x 64 x C products at once: acc[q][i][j] += sum_c L_q[c*P + m0_q + ..] * R_q[c*P + n0_q + ..]; wave w owns the
-// 32 x 32 block (w >> 1, w & 1) of every product.  Round 3: the slabs arrive by LDS-DMA, two slabs ahead of the MFMAs in a
-// ring of three buffers, one barrier per slab (round 2: 16-deep slabs through registers, two barriers each - the kernel
+// 32 x 32 block (w >> 1, w & 1) of every product.  Round 3: the slabs arrive by LDS-DMA, GNB - 1 slabs ahead of the MFMAs in
+// a ring of GNB buffers, one barrier per slab (round 2: 16-deep slabs through registers, two barriers each - the kernel
 // waited for memory latency 16 times per tile with 16 MFMAs per wave in between).  One product runs on 32-deep slabs, the
-// pair of the backward pass on 16-deep ones: four copies per wave and slab and 48 KB of LDS either way.
+// pair of the backward pass on 16-deep ones: four copies per wave and slab and the same LDS either way.
 // Slab image [k][64], the 16-B chunks of odd k rows swapped in pairs 16 floats apart (column ^ 16): the MFMA operand reads
 // (lanes 0-31 of a ds_read_b32 = two k rows x 16 columns) are conflict-free.  Columns beyond P fetch the row's last valid
 // chunk instead (finite duplicates; their products land in rows / columns nobody stores).
-constexpr int GNB = 3;                          // ring length
-constexpr int GRING = GNB * 2 * 32 * 64;        // floats: 48 KB
+#ifndef TL_GNB
+#define TL_GNB 2
+#endif
+// Ring length of the Gram products.  Two buffers (the copy of slab s + 1 travels under the MFMAs of slab s) leave room for
+// four work-groups per CU next to the epilogue tiles; three buffers (two slabs ahead) for three - measured at N = 64, 14 x 14:
+// 41 + 61 us against 44 + 71 us: these launches hide latency with neighbours, not with depth.
+constexpr int GNB = TL_GNB;
 constexpr int EPS = 68;                         // row stride of the epilogue tiles (16-B aligned rows, conflict-free writes)
+constexpr int GRING = GNB * 2 * 32 * 64 > 2 * 64 * EPS ? GNB * 2 * 32 * 64 : 2 * 64 * EPS;   // floats: 48 KB
 struct GramOp {
   const float* L;
   const float* Rm;
@@ -275,13 +315,13 @@ __device__ __forceinline__ void gram_core(f32x4 (&acc)[NP][2][2], const GramOp (
   constexpr int PER = NP * 2 * PIECES;          // copies per wave and slab (4)
   const int S = C / GKT;
   issue(0);
-  if (S > 1) issue(1);
+  if (S > 1 && GNB > 2) issue(1);
   const int sw = 16 * (lq & 1);
   for (int s = 0; s < S; ++s) {
-    if (TL_ABL & 32) wait_vm<0>();
+    if ((TL_ABL & 32) || GNB == 2) wait_vm<0>();
     else if (s + 1 < S) wait_vm<PER>(); else wait_vm<0>();   // this wave's pieces of slab s have landed
     lds_barrier();                                      // ... everybody's; and everybody is done reading slab s - 1
-    if (s + 2 < S && !(TL_ABL & 32)) issue(s + 2);      // into the buffer slab s - 1 occupied
+    if (s + GNB - 1 < S && !(TL_ABL & 32)) issue(s + GNB - 1);   // into the buffer slab s - 1 occupied
     const float* buf = ring + (s % GNB) * NP * 2 * SLAB;
     if (TL_ABL & 16) {
 #pragma unroll
@@ -333,10 +373,11 @@ __device__ __forceinline__ void tl_finish(const float* __restrict__ lpart, const
   for (int b = threadIdx.x; b < B; b += TB) {
     float s = 0.f;
     for (int k = 0; k < strips; ++k) s += lpart[(size_t)b * strips + k];
-    const float ln = s / (cnt[b] + 1e-6f);
+    const float cb = cnt_of(cnt, b);
+    const float ln = s / (cb + 1e-6f);
     loss_n[b] = ln;
-    pos_num[b] = cnt[b];
-    pos_mean[b] = cnt[b] / (float)P / (float)P;     // reference: mean(-1).mean(-1) in fp32 (< 1 ulp apart)
+    pos_num[b] = cb;
+    pos_mean[b] = cb / (float)P / (float)P;         // reference: mean(-1).mean(-1) in fp32 (< 1 ulp apart)
     acc += ln;
   }
   acc = wave_sum(acc);
@@ -680,7 +721,6 @@ __global__ void __launch_bounds__(TB) k_tl_strip(pixpro_problem pb, Dirs D, TlWs
     }
   };
   const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-  auto crow = [&](int m, int r) { return wave * 16 * MW + 16 * m + 4 * lq + r; };
   f32x4 acc[MW][4];
 #pragma unroll
   for (int m = 0; m < MW; ++m)
@@ -764,7 +804,7 @@ __global__ void __launch_bounds__(TB) k_tl_strip(pixpro_problem pb, Dirs D, TlWs
       if (lane == 0) w.lpart[(size_t)b * ns + sx] = s;
     }
     if (!want_grad) return;
-    const float gs = g0 / (w.cnt[b] + 1e-6f);
+    const float gs = g0 / (cnt_of(w.cnt, b) + 1e-6f);
     float tg[4];
 #pragma unroll
     for (int nn = 0; nn < 4; ++nn) tg[nn] = gs * tc[nn];
@@ -817,11 +857,8 @@ int run_tiled_c(const pixpro_problem& pb, const Dirs& D, const TlWs& w, float* l
   const bool want_grad = D.d[0].dx != nullptr;
   const float g0 = pb.grad_scale * -2.f / (float)N;
   const TlFin fin{loss_n, loss, pos_num, pos_mean, B, nt};
-  hipLaunchKernelGGL(k_tl_rnorms, dim3(nt, B, 3), dim3(TB), 0, st, D, w.rx, w.rv, w.rk, w.cnt, w.zero, N, C, P,
-                     pb.normalize_k);
-  TL_CHECK("k_tl_rnorms");                 // also zeroes the counts k_tl_prep accumulates
-  hipLaunchKernelGGL(k_tl_prep, dim3(B, PREP_S), dim3(TB), 0, st, pb, D, w.bits, w.cnt);
-  TL_CHECK("k_tl_prep");
+  hipLaunchKernelGGL(k_tl_pre, dim3((6 + PREP_S) * B), dim3(TB), 0, st, pb, D, w);
+  TL_CHECK("k_tl_pre");
   hipLaunchKernelGGL(k_tl_gram<0>, dim3(nt * (nt + 1) / 2 * B), dim3(TB), 0, st, D, w, N, C, P, pb.p, pb.clamp, fin);
   TL_CHECK("k_tl_gram<0>");
   hipLaunchKernelGGL((k_tl_strip<MW, 0>), dim3(nt * B), dim3(TB), 0, st, pb, D, w, g0, (int)want_grad, nt);
