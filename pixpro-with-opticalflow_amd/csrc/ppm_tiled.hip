@@ -267,7 +267,7 @@ __device__ __forceinline__ void lds_barrier() {          // LDS traffic of this 
 // 41 + 61 us against 44 + 71 us: these launches hide latency with neighbours, not with depth.
 constexpr int GNB = TL_GNB;
 constexpr int EPS = 68;                         // row stride of the epilogue tiles (16-B aligned rows, conflict-free writes)
-constexpr int GRING = GNB * 2 * 32 * 64 > 2 * 64 * EPS ? GNB * 2 * 32 * 64 : 2 * 64 * EPS;   // floats: 48 KB
+constexpr int GRING = GNB * 2 * 32 * 64 > 2 * 64 * EPS ? GNB * 2 * 32 * 64 : 2 * 64 * EPS;   // floats: 34 KB at GNB = 2
 struct GramOp {
   const float* L;
   const float* Rm;
@@ -410,7 +410,7 @@ __device__ __forceinline__ void tile_rows_out(const float* tile, float* __restri
 
 template <int MODE>
 __global__ void __launch_bounds__(TB) k_tl_gram(Dirs D, TlWs w, int N, int C, int P, float p, float clampv, TlFin fin) {
-  __shared__ __attribute__((aligned(16))) float ring[GRING];      // 48 KB: slab ring, then the epilogue tiles
+  __shared__ __attribute__((aligned(16))) float ring[GRING];      // slab ring, then the epilogue tiles
   static_assert(GRING >= 2 * 64 * EPS, "two epilogue tiles fit in the slab ring");
   // The loss reduction needs every strip of the launch before (k_tl_strip<0>) and nothing of this one: when gradients
   // are wanted it rides in the first block of this launch instead of a one-block launch of its own.
