@@ -13,6 +13,7 @@ run() {  # name, counters
 run sq1 "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS"
 run sq2 "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_ANY"
 run grbm "GRBM_GUI_ACTIVE"
+run mfma "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_F32 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CU_CYCLES" || true
 run fetch "FETCH_SIZE"
 run write "WRITE_SIZE"
 python3 - "$OUT" <<'PY'
@@ -21,7 +22,7 @@ out = sys.argv[1]
 vals = collections.defaultdict(lambda: collections.defaultdict(list))
 for path in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
     for row in csv.DictReader(open(path)):
-        m = re.search(r"\b(k_\w+|ppm_\w+)", row["Kernel_Name"])
+        m = re.search(r"\b(k_\w+(<[^>]*>)?|ppm_\w+)", row["Kernel_Name"])
         if m:
             vals[m.group(1)][row["Counter_Name"]].append(float(row["Counter_Value"]))
 with open(os.path.join(out, "pmc_summary.txt"), "w") as fh:
@@ -29,5 +30,10 @@ with open(os.path.join(out, "pmc_summary.txt"), "w") as fh:
         fh.write(k + "\n")
         for c, v in sorted(cs.items()):
             fh.write(f"  {c:28s} median {statistics.median(v):16.1f}  n={len(v)}\n")
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in cs and "GRBM_GUI_ACTIVE" in cs:
+            # rocprofv3's MfmaUtil: matrix-core busy cycles (summed over the 1024 SIMDs) over active cycles x 1024 SIMDs.  The
+            # per-dispatch GRBM_GUI_ACTIVE of the csv is the SUM over the 8 XCDs (8 x the kernel's cycles), hence the / 8.
+            util = statistics.median(cs["SQ_VALU_MFMA_BUSY_CYCLES"]) / (statistics.median(cs["GRBM_GUI_ACTIVE"]) / 8 * 1024) * 100
+            fh.write(f"  {'MFMA utilisation (derived)':28s} {util:23.1f} %\n")
 print(open(os.path.join(out, "pmc_summary.txt")).read())
 PY
