@@ -150,7 +150,9 @@ int pixpro_fbc_mask(const float* flow_fwd, const float* flow_bwd, uint8_t* mask,
  * permute of util.py:183) -> composed flows [N,2,Hf,Wf] and masks uint8 [N,Hf,Wf]
  * (Hf,Wf = 8h,8w if flow_up else h,w).  masks nullable (alpha None).  invalid_count
  * (nullable) int32 [2*N]: number of invalid pixels per sample (fwd then bwd), the numerator
- * of calc_mask_ratio (util.py:360-366).  F1 == 1 (nframe 2): two launches (flows + certified masks; the tiles the
+ * of calc_mask_ratio (util.py:360-366).  Any alignment is accepted; the fast F1 == 1 route wants the flows 8-B and the
+ * masks 2-B aligned (torch allocations are) and falls back to a one-thread-per-pixel kernel otherwise (same bits).
+ * F1 == 1 (nframe 2): two launches (flows + certified masks; the tiles the
  * certificate cannot settle), the only HBM traffic is the low-res read and the output write; F1 > 1: one chain launch
  * (up-sampling evaluated lazily) + one mask launch (see pixpro_flow_prepare_ws for the certified mask route).  Both of ATen's CPU bilinear up-sampling orders are reproduced
  * (switch at 8h + 8w = 128).  No workspace.  The environment variable PIXPRO_FLOW_PATH = auto | certified | staged

@@ -139,7 +139,8 @@ int pixpro_ppm_loss(const pixpro_problem* pb, const pixpro_dir* dirs, float* los
   bool aligned = true;
   for (int d = 0; d < pb->ndir; ++d) {
     const pixpro_dir& q = dirs[d];
-    const uintptr_t bits = (uintptr_t)q.x | (uintptr_t)q.v | (uintptr_t)q.k | (uintptr_t)q.dx | (uintptr_t)q.dv;
+    const uintptr_t bits = (uintptr_t)q.x | (uintptr_t)q.v | (uintptr_t)q.k | (uintptr_t)q.dx | (uintptr_t)q.dv |
+                           (uintptr_t)q.pred;      // 16 B per lane loads / stores / LDS-DMA in the MFMA paths
     if (bits & 15) aligned = false;
   }
   if (pb->layout == 1 && !(fused_supported(*pb) && aligned))
@@ -149,7 +150,7 @@ int pixpro_ppm_loss(const pixpro_problem* pb, const pixpro_dir* dirs, float* los
     return run_finalize(loss_n, loss, pb->N * pb->ndir, pb->N, (hipStream_t)stream);
   }
   if (!workspace) return bad("this shape takes a multi-launch path and needs a workspace");
-  // grids beyond 64 positions (14 x 14 at 448^2 crops): the tiled MFMA path, 6 launches; anything else: the staged path
+  // grids beyond 64 positions (14 x 14 at 448^2 crops): the tiled MFMA path, 5 launches; anything else: the staged path
   if (tiled_supported(*pb) && aligned && !getenv("PIXPRO_NO_TILED"))
     return run_tiled(*pb, dirs, loss_n, pos_num, pos_mean, loss, workspace, workspace_bytes, (hipStream_t)stream);
   return run_generic(*pb, dirs, loss_n, pos_num, pos_mean, loss, workspace, workspace_bytes, (hipStream_t)stream, 0);

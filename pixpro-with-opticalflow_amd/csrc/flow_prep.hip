@@ -1375,7 +1375,11 @@ int run_flow_prepare(const float* lo_fwd, const float* lo_bwd, float* flow_fwd, 
   const dim3 grid((Wf + TX - 1) / TX, (Hf + TY - 1) / TY, 1);
   const bool tiled = flow_up && up8_separable(h, w) && 2 * N <= 65535 && grid.y <= 65535;
   if (F1 == 1) {
-    if (tiled) {
+    // k_prepare_cert stores two pixels per lane: 8-B flow stores, 2-B mask stores.  Outputs that are not aligned for that
+    // (views at odd offsets) take the one-thread-per-pixel kernel, same bits.
+    const bool pair_aligned = (((uintptr_t)flow_fwd | (uintptr_t)flow_bwd) & 7) == 0 &&
+                              (!mask_fwd || (((uintptr_t)mask_fwd | (uintptr_t)mask_bwd) & 1) == 0);
+    if (tiled && pair_aligned) {
       // PIXPRO_FLOW_PATH: auto (default) | certified (hand over only what the table cannot cover) | staged (hand over all):
       // identical results, a knob for the tests and for timing the two paths
       const char* path = getenv("PIXPRO_FLOW_PATH");

@@ -226,6 +226,39 @@ def test_flow_prepare_without_workspace_equals_certified_route(dev):
                 nv.ptr(cnt), N, F1, hw[0], hw[1], 1, 0.01, 0.5, nv.ptr(small), 64, nv.stream())
 
 
+def test_flow_prepare_unaligned_outputs_and_workspace(dev):
+    """The nframe = 2 kernel stores two pixels per lane (8-B flow stores, 2-B mask stores).  Output views at odd offsets take
+    the one-thread-per-pixel kernel instead - the same bits - and a misaligned workspace is refused (advisor r2)."""
+    from contrast import util, _native as nv
+    from recipes import smooth_flow
+    gen = torch.Generator().manual_seed(9)
+    N, hw = 2, (45, 80)
+    fw = smooth_flow((N, 1, 2, *hw), 0.3, gen)
+    bw = -fw.flip(1) + smooth_flow((N, 1, 2, *hw), 0.03, gen)
+    size = torch.tensor([8 * hw[0], 8 * hw[1]])
+    (f, _, mf), (b, _, mb) = util.apply_optical_flow(_data(fw, bw, size, 2, dev), None, _args(True))
+    lo_f, lo_b = fw.to(dev).contiguous(), bw.to(dev).contiguous()
+    nf, nm = f.numel(), mf.numel()
+    fbuf = torch.empty(2 * nf + 8, dtype=torch.float32, device=dev)
+    mbuf = torch.empty(2 * nm + 8, dtype=torch.uint8, device=dev)
+    f2, b2 = fbuf[1:1 + nf].view(f.shape), fbuf[nf + 3:2 * nf + 3].view(f.shape)          # 4-B aligned only
+    mf2, mb2 = mbuf[1:1 + nm].view(mf.shape), mbuf[nm + 3:2 * nm + 3].view(mf.shape)     # odd addresses
+    cnt = torch.empty(2 * N, dtype=torch.int32, device=dev)
+    assert nv.ptr(f2).value % 8 == 4 and nv.ptr(mf2).value % 2 == 1
+    nv.call("pixpro_flow_prepare", nv.ptr(lo_f), nv.ptr(lo_b), nv.ptr(f2), nv.ptr(b2), nv.ptr(mf2), nv.ptr(mb2),
+            nv.ptr(cnt), N, 1, hw[0], hw[1], 1, 0.01, 0.5, nv.stream())
+    assert torch.equal(f, f2) and torch.equal(b, b2)
+    assert torch.equal(mf.as_subclass(torch.Tensor).view(torch.uint8), mf2)
+    assert torch.equal(mb.as_subclass(torch.Tensor).view(torch.uint8), mb2)
+    assert torch.equal(cnt[:N].cpu(), (mf2 == 0).sum((-1, -2)).int().cpu())
+    ws = torch.empty(2 * N * hw[0] * hw[1] * 16 * 3 + 64, dtype=torch.uint8, device=dev)
+    lo3 = torch.cat([lo_f, lo_f, lo_f], 1).contiguous()
+    nbytes = nv.load().pixpro_flow_prepare_workspace_bytes(N, 3, hw[0], hw[1], 1)
+    with pytest.raises(RuntimeError):
+        nv.call("pixpro_flow_prepare_ws", nv.ptr(lo3), nv.ptr(lo3), nv.ptr(f), nv.ptr(b), nv.ptr(mf2), nv.ptr(mb2),
+                nv.ptr(cnt), N, 3, hw[0], hw[1], 1, 0.01, 0.5, nv.ptr(ws[4:]), nbytes, nv.stream())
+
+
 @pytest.mark.parametrize("nfr,hw", [(2, (37, 53)), (3, (37, 53)), (2, (11, 29)), (4, (23, 9))])
 def test_flow_prepare_ragged_sizes_vs_oracle(dev, nfr, hw):
     """Frame sizes that are no multiple of the 64 x 80 (64 x 40) tiles in either direction: partial tiles, partial
