@@ -26,7 +26,8 @@ namespace {
 
 #ifndef TL_ABL
 #define TL_ABL 0                 // timing ablations (tools/tl_abl.sh): strips: 1 strip<1> epilogue traffic off, 2 no MFMA, 4 no copies;
-                                 // Gram kernels: 8 no epilogue stores, 16 no MFMA, 32 no copies after the first two slabs
+                                 // Gram kernels: 8 no epilogue stores, 16 no MFMA, 32 no copies after the first two slabs;
+                                 // 64: strip operands re-read from the first slab (fetch served from cache)
 #endif
 constexpr int TB = 256;          // threads per work-group: 4 waves
 
@@ -580,7 +581,7 @@ __device__ __forceinline__ void strip_gemm(f32x4 (&acc)[MW][4], int P, int n0, i
   const int S = (P + SK - 1) / SK;
   auto issue = [&](int s) {
     float* buf = ring + (s % SNB) * R::SLAB;
-    const int k0 = s * SK;
+    const int k0 = (TL_ABL & 64) ? 0 : s * SK;   // ablation 64: every slab re-reads the first one (cache hits): what does the fetch cost?
     const bool tail = k0 + SK > P;             // uniform: only the last slab of P = 196 has k chunks beyond P
 #pragma unroll
     for (int e = 0; e < MW; ++e)
