@@ -238,10 +238,19 @@ __device__ __forceinline__ void xcd_item(int per, int B, int& b, int& item) {
 // reads (the same involution on both).  The copies are counted in vmcnt; nothing orders them against LDS reads except the
 // issuing wave's s_waitcnt vmcnt(n) followed by a barrier, so the loops below use raw s_barrier (a __syncthreads() would
 // drain every copy in flight with vmcnt(0)).
+// The copy is issued from inline assembly on purpose: hipcc tracks an LDS-DMA it knows about as a pending LDS write and,
+// where it cannot prove that a later ds_read touches another buffer of the ring, puts s_waitcnt vmcnt(0) in front of the
+// read - which drains the slabs that were requested AHEAD as well (found in the strip kernels' ISA in round 3: every slab
+// waited for the copies issued in the same iteration).  The waits are placed by hand below, by count.  M0 (the LDS base of
+// the copy) is saved and restored inside the statement.
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
-typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 __device__ __forceinline__ void dma16(const float* src, float* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)lds_wave_base, 16, 0, 0);
+  const unsigned lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr_t)lds_wave_base);
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(src), "s"(lds)
+               : "memory");
 }
 template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -627,10 +636,12 @@ __device__ __forceinline__ void strip_gemm(f32x4 (&acc)[MW][4], int P, int n0, i
       for (int nn = 0; nn < 4; ++nn)
         if (nn < nlive) {                // column tiles beyond this strip issue no MFMA (uniform)
 #pragma unroll
-          for (int m = 0; m < MW; ++m)
-            if (TL_ABL & 2) acc[m][nn][0] += (ks == 0 ? av[m].x : ks == 1 ? av[m].y : ks == 2 ? av[m].z : av[m].w) + bv[nn].x;
-            else acc[m][nn] = mfma16(ks == 0 ? av[m].x : ks == 1 ? av[m].y : ks == 2 ? av[m].z : av[m].w,
-                                ks == 0 ? bv[nn].x : ks == 1 ? bv[nn].y : ks == 2 ? bv[nn].z : bv[nn].w, acc[m][nn]);
+          for (int m = 0; m < MW; ++m) {
+            const float a = ks == 0 ? av[m].x : ks == 1 ? av[m].y : ks == 2 ? av[m].z : av[m].w;
+            const float b = ks == 0 ? bv[nn].x : ks == 1 ? bv[nn].y : ks == 2 ? bv[nn].z : bv[nn].w;
+            if (TL_ABL & 2) acc[m][nn][0] += a + b;
+            else acc[m][nn] = mfma16(a, b, acc[m][nn]);
+          }
         }
   }
   lds_barrier();                                        // the ring may be refilled by the next product
