@@ -86,6 +86,10 @@ def parse():
                          "with several: every SyncBN collective of a process goes through ProcessGroupNCCL's one internal stream "
                          "in host order, so with >1 rank the two branches would serialise at every layer anyway")
     ap.add_argument("--no-overlap-momentum", dest="overlap_momentum", action="store_const", const="off")
+    ap.add_argument("--key-bn-group", action="store_true",
+                    help="with several ranks: the key encoder's SyncBN collectives on a process group of their own (second RCCL "
+                         "communicator) and the key branch on its second stream (--overlap-momentum auto then means on); "
+                         "unmeasured on hardware so far, off by default")
     ap.add_argument("--bn-view-batch", action="store_true",
                     help="both views of an encoder in one pass with per-view BatchNorm statistics: half the SyncBN collectives "
                          "(same statistics); unmeasured on more than one GPU, off by default")
@@ -120,7 +124,9 @@ def model_args(a, world):
         argv.append("--fused-bn")
     if a.bn_view_batch:
         argv.append("--bn-view-batch")
-    a.overlap_momentum = a.overlap_momentum == "on" or (a.overlap_momentum == "auto" and world == 1)
+    a.overlap_momentum = a.overlap_momentum == "on" or (a.overlap_momentum == "auto" and (world == 1 or a.key_bn_group))
+    if a.key_bn_group:
+        argv.append("--key-bn-group")
     if a.overlap_momentum:
         argv.append("--overlap-momentum")
     args = option.parse_option(argv=argv)
@@ -593,7 +599,8 @@ def main():
                                    f"p=2, transform_layer=1, LARS, fp32",
                        "batch_norm": ("fused HIP SyncBN+ReLU" + (", two views per pass" if a.bn_view_batch else ""))
                                      if a.fused_bn else "torch (Sync)BatchNorm",
-                       "key_branch": "second HIP stream" if a.overlap_momentum else "same stream",
+                       "key_branch": ("second HIP stream" + (", own SyncBN process group" if a.key_bn_group and world > 1 else ""))
+                                     if a.overlap_momentum else "same stream",
                        "miopen": f"immediate mode; {miopen_note}",
                        "flow_mode": "lazy (flow + mask evaluated at the loss sample points)" if a.lazy_flow else "dense",
                        "per_gpu_batch": a.batch, "global_batch": a.batch * world,

@@ -124,9 +124,20 @@ class PixPro(BaseModel):
         # PixPro.py:289-292 (in-place on the children).  --fused-bn: the HIP SyncBN with ReLU / residual add folded in
         self._convert_bn = (FusedSyncBatchNorm.convert if getattr(args, "fused_bn", False)
                             else nn.SyncBatchNorm.convert_sync_batchnorm)
+        # With several ranks the SyncBN collectives of a process group are queued on that group's ONE internal stream in host
+        # order: the key branch on its second HIP stream (overlap_momentum) would wait head-of-line behind the online
+        # branch's collectives and the other way round.  --key-bn-group gives the key encoder's BatchNorm layers a process
+        # group of their own (same ranks, a second RCCL communicator with its own stream): the two branches then exchange
+        # statistics independently.  Same numbers - only which communicator carries them changes.
+        self.key_bn_group = None
+        if sync_bn and getattr(args, "key_bn_group", False) and torch.distributed.is_available() \
+                and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            self.key_bn_group = torch.distributed.new_group()
         if sync_bn:
-            for m in (self.encoder, self.encoder_k, self.projector, self.projector_k):
+            for m in (self.encoder, self.projector):
                 self._convert_bn(m)
+            for m in (self.encoder_k, self.projector_k):
+                self._convert_bn(m, self.key_bn_group)
 
         world = get_world_size() if is_initialized() else 1
         self._steps_per_epoch = args.num_instances * 1. / world / args.batch_size

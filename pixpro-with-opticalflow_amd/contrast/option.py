@@ -85,6 +85,9 @@ _FLAGS = [
     (("--lazy-flow",), dict(action="store_true", help="evaluate flow chain + consistency mask inside the loss kernel at "
                                                       "its sample points instead of preparing dense tensors (same results)")),
     (("--channels-last",), dict(action="store_true")),
+    (("--key-bn-group",), dict(action="store_true", help="SyncBN collectives of the key (momentum) encoder on a process "
+                                "group of their own (second RCCL communicator): with several ranks the two branches of "
+                                "--overlap-momentum then do not queue behind each other's statistics exchanges")),
     (("--overlap-momentum",), dict(action="store_true", help="run the key (momentum) branch on a second HIP stream, "
                                                              "concurrently with the online branch")),
     (("--fused-bn",), dict(action="store_true", help="HIP (Sync)BatchNorm with the ReLU / residual add folded in "

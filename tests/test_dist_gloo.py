@@ -101,3 +101,48 @@ def test_two_rank_ddp_step(tmp_path):
     assert r["same_grad"] and r["same_w"], "DDP must leave both ranks with identical averaged gradients / weights"
     assert r["distinct_shards"] and r["tmax"] == 2.0 and r["loss_finite"] and r["gnorm"] > 0
     assert r["pos_shape"] == (2,)
+
+
+def _worker_groups(rank, world, port, out):
+    for p in (ROOT, PKG, os.path.join(ROOT, "tests", "golden")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import types
+    from contrast import resnet
+    from contrast.models import PixPro
+    from contrast.sync_bn import FusedSyncBatchNorm
+    res = {}
+    for fused in (False, True):
+        args = types.SimpleNamespace(pixpro_p=2.0, pixpro_momentum=0.99, pixpro_pos_ratio=0.7, pixpro_clamp_value=0.0,
+                                     pixpro_transform_layer=1, pixpro_ins_loss_weight=0.0, output_dir="/tmp", num_instances=16,
+                                     batch_size=2, epochs=2, start_epoch=1, feature_dim=256, head_type="early_return",
+                                     sync_bn=True, fused_bn=fused, key_bn_group=True)
+        model = PixPro(resnet.__dict__["resnet18"], args)
+        kind = FusedSyncBatchNorm if fused else torch.nn.SyncBatchNorm
+        key = [m for part in (model.encoder_k, model.projector_k) for m in part.modules() if isinstance(m, kind)]
+        onl = [m for part in (model.encoder, model.projector) for m in part.modules() if isinstance(m, kind)]
+        g = model.key_bn_group
+        t = torch.tensor([1.0 + rank])
+        dist.all_reduce(t, group=g)                       # the second group is a working communicator over the same ranks
+        res[fused] = dict(n_key=len(key), n_onl=len(onl), key_ok=all(m.process_group is g for m in key),
+                          onl_ok=all(m.process_group is None for m in onl), distinct=g is not None and g is not dist.group.WORLD,
+                          size=dist.get_world_size(g), sum=t.item())
+    if rank == 0:
+        torch.save(res, out)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_key_branch_syncbn_gets_its_own_process_group(tmp_path):
+    """--key-bn-group: the BatchNorm layers of the key (momentum) encoder and projector exchange their statistics over a
+    second process group (own RCCL communicator and stream), the online branch's over the default one - plumbing only:
+    SyncBN itself needs the GPU (tests/test_gpu_sync_bn.py runs the fused module over explicit groups)."""
+    out = str(tmp_path / "groups.pt")
+    mp.spawn(_worker_groups, args=(2, _free_port(), out), nprocs=2, join=True)
+    r = torch.load(out)
+    for fused in (False, True):
+        q = r[fused]
+        assert q["n_key"] > 10 and q["n_key"] == q["n_onl"]
+        assert q["key_ok"] and q["onl_ok"] and q["distinct"] and q["size"] == 2 and q["sum"] == 3.0

@@ -171,6 +171,53 @@ def test_two_ranks_equal_one_process_on_the_whole_batch(dev, tmp_path):
         assert torch.allclose(o["rm"].to(dev), rm, rtol=1e-5, atol=1e-6) and torch.allclose(o["rv"].to(dev), rv, rtol=1e-5, atol=1e-6)
 
 
+def _rank_model(rank, world, port, path):
+    for p in (ROOT, PKG):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import types
+    from contrast import resnet
+    from contrast.models import PixPro
+    from contrast.synthetic import make_batch
+    dev = torch.device("cuda:0")
+    out = {}
+    for own_group in (False, True):
+        args = types.SimpleNamespace(pixpro_p=2.0, pixpro_momentum=0.99, pixpro_pos_ratio=0.7, pixpro_clamp_value=0.0,
+                                     pixpro_transform_layer=1, pixpro_ins_loss_weight=0.0, output_dir="/tmp", num_instances=64,
+                                     batch_size=4, epochs=2, start_epoch=1, feature_dim=256, head_type="early_return",
+                                     sync_bn=True, fused_bn=True, key_bn_group=own_group, overlap_momentum=own_group)
+        torch.manual_seed(0)
+        model = PixPro(resnet.__dict__["resnet18"], args).to(dev).to(memory_format=CL).train()
+        data = make_batch(4, image_size=64, n_frames=2, frame_hw=(48, 64), device=dev, seed=1234 + rank, flow_up=False)
+        size = (48, 64)
+        c1 = [data[2], [data[5][1][:, 0], size, None]]
+        c2 = [data[3], [data[5][2][:, 0], size, None]]
+        loss, _ = model(data[0].contiguous(memory_format=CL), data[1].contiguous(memory_format=CL), c1, c2)
+        loss.backward()
+        torch.cuda.synchronize()
+        bn_k = next(m for m in model.encoder_k.modules() if getattr(m, "fused", False))
+        out[own_group] = dict(loss=loss.item(), g=model.value_transform.weight.grad.cpu().clone(),
+                              rm=bn_k.running_mean.cpu().clone(), has_group=model.key_bn_group is not None)
+    if rank == 0:
+        torch.save(out, path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_key_branch_on_its_own_process_group_gives_the_same_step(dev, tmp_path):
+    """--key-bn-group with the key branch on its second stream, two ranks (gloo, sharing the GPU): the SyncBN statistics of
+    the key encoder travel over a second process group - loss, gradients and running statistics are those of the plain
+    step (the collectives of the two branches no longer share one queue)."""
+    path = str(tmp_path / "model.pt")
+    mp.spawn(_rank_model, args=(2, _free_port(), path), nprocs=2, join=True)
+    r = torch.load(path)
+    assert r[True]["has_group"] and not r[False]["has_group"]
+    assert abs(r[True]["loss"] - r[False]["loss"]) <= 1e-6 * max(1.0, abs(r[False]["loss"]))
+    close(r[True]["g"], r[False]["g"], rel=1e-5)
+    assert torch.equal(r[True]["rm"], r[False]["rm"])
+
+
 def test_model_step_with_fused_bn_matches_stock(dev):
     """ResNet-18 PixPro step (cfg-1 shapes), same weights and inputs, stock BatchNorm + ReLU vs the fused modules."""
     import types
