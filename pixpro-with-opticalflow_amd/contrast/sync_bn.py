@@ -178,6 +178,26 @@ class FusedSyncBatchNorm(nn.modules.batchnorm._BatchNorm):
         self.process_group = process_group
         if momentum is None:
             raise NotImplementedError("cumulative moving average (momentum=None) is not provided")
+        # `num_batches_tracked` is bookkeeping here (the momentum is fixed): a device-side `add_` per forward call is one
+        # tiny launch per layer - 216 per ResNet-50 step, 1.6 ms.  The increments are collected on the host and applied
+        # whenever the buffer is looked at (attribute access, state_dict): same values, no launches in the step.
+        self._nbt_pending = 0
+        self.register_state_dict_pre_hook(lambda module, prefix, keep_vars: module._flush_counter())
+
+    def _flush_counter(self):
+        nbt = self._buffers.get("num_batches_tracked")
+        if self._nbt_pending and nbt is not None:
+            nbt.add_(self._nbt_pending)
+        self._nbt_pending = 0
+
+    def __getattr__(self, name):
+        if name == "num_batches_tracked" and self.__dict__.get("_nbt_pending"):
+            self._flush_counter()
+        return super().__getattr__(name)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._nbt_pending = 0                   # a loaded counter replaces whatever was pending
+        return super()._load_from_state_dict(*args, **kwargs)
 
     def _check_input_dim(self, input):
         if input.dim() not in (2, 4):
@@ -186,8 +206,8 @@ class FusedSyncBatchNorm(nn.modules.batchnorm._BatchNorm):
     def forward(self, input, residual=None, relu=False):
         self._check_input_dim(input)
         if self.training or not self.track_running_stats:
-            if self.training and self.track_running_stats and self.num_batches_tracked is not None:
-                self.num_batches_tracked.add_(_VIEW_GROUPS)
+            if self.training and self.track_running_stats and self._buffers.get("num_batches_tracked") is not None:
+                self._nbt_pending += _VIEW_GROUPS
             rm = self.running_mean if (self.training and self.track_running_stats) else None
             rv = self.running_var if (self.training and self.track_running_stats) else None
             return _FusedBN.apply(input, self.weight, self.bias, residual, rm, rv, self.momentum, self.eps, relu,
