@@ -401,6 +401,20 @@ def test_tiled_path_shapes_vs_staged(dev, N, C, H, W, p):
         close(a, b, rel=1e-4 if p >= 1.0 else 2e-3)
 
 
+def test_tiled_path_is_bitwise_repeatable(dev):
+    """The tiled path orders its LDS-DMA copies against the LDS reads by hand (counted s_waitcnt vmcnt + raw barriers, copies
+    issued from inline assembly): a read that overtakes its copy would pass a single comparison whenever the copy happens
+    to land first.  60 launches on the same inputs (two batch sizes, so that work-group placement varies) must agree bit
+    for bit - the reductions run in a fixed order, so any difference is a race."""
+    for N in (64, 17):
+        P = _random_problem(dev, N, 256, 14, 14, 96, 128, seed=500 + N)
+        first, gfirst = _run_hip(dev, P, generic=False)
+        for _ in range(30):
+            out, g = _run_hip(dev, P, generic=False)
+            assert out[0].item() == first[0].item() and torch.equal(out[1], first[1])
+            assert all(torch.equal(a, b) for a, b in zip(g, gfirst))
+
+
 def test_tiled_equals_staged_and_properties(dev):
     """14 x 14 grid: the tiled path against the staged path on the device, plus the size-independent properties
     (all-false mask -> zero loss and gradients, linearity in the upstream gradient, forward-only call)."""
