@@ -168,6 +168,10 @@ class _FusedBN(torch.autograd.Function):
         return dx, gw, gb, dres, None, None, None, None, None, None, None
 
 
+def _flush_counter_hook(module, prefix, keep_vars):
+    module._flush_counter()
+
+
 class FusedSyncBatchNorm(nn.modules.batchnorm._BatchNorm):
     """Drop-in for nn.BatchNorm2d / nn.SyncBatchNorm with optional fused tail: `bn(x, residual=None, relu=False)`."""
 
@@ -182,7 +186,7 @@ class FusedSyncBatchNorm(nn.modules.batchnorm._BatchNorm):
         # tiny launch per layer - 216 per ResNet-50 step, 1.6 ms.  The increments are collected on the host and applied
         # whenever the buffer is looked at (attribute access, state_dict): same values, no launches in the step.
         self._nbt_pending = 0
-        self.register_state_dict_pre_hook(lambda module, prefix, keep_vars: module._flush_counter())
+        self.register_state_dict_pre_hook(_flush_counter_hook)     # a plain function: the module stays picklable
 
     def _flush_counter(self):
         nbt = self._buffers.get("num_batches_tracked")
