@@ -55,6 +55,27 @@ def pmc_traffic(kernel, a):
     return int(t[kernel]["hbm_bytes_per_image"] * a.batch), f"{PMC_FILE}, collected at N={t.get('N', 256)}, scaled to N={a.batch}"
 
 
+def pmc_mfma_util(a):
+    """MFMA utilisation of the PPM/loss launches from the committed PMC summaries (rocprofv3's MfmaUtil: matrix-core busy
+    cycles over the kernel's cycles x 1024 SIMDs; tools/pmc_kernel.sh).  A kept figure for the configuration it was
+    collected on (N = 256 at 7 x 7, N = 64 at 14 x 14), not a counter read during this run.  {kernel: percent}, source."""
+    import glob
+    import re
+    name = "ppm_fused_n256" if a.image_size == 224 else "ppm_tiled_14x14_n64" if a.image_size == 448 else None
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_{name}.txt"))) if name else []
+    if not found:
+        return None, None
+    out, cur = {}, None
+    for line in open(found[-1]):
+        if not line.startswith(" "):
+            cur = line.strip()
+        else:
+            m = re.match(r"\s+MFMA utilisation \(derived\)\s+([\d.]+) %", line)
+            if m and float(m.group(1)) > 0:
+                out[cur] = float(m.group(1))
+    return (out or None), os.path.relpath(found[-1], ROOT)
+
+
 def cpu_model():
     try:
         with open("/proc/cpuinfo") as fh:
@@ -547,7 +568,9 @@ def main():
                                    "traffic_source": pmc_traffic("ppm_loss", a)[1],
                                    "ms_per_launch": round(ms["ppm_loss"], 4),
                                    "algorithmic_flops_per_launch": int(f_ppm * a.batch),
-                                   "hbm_frac": round(b_ppm * a.batch / t / HBM_PEAK, 4)}
+                                   "hbm_frac": round(b_ppm * a.batch / t / HBM_PEAK, 4),
+                                   "mfma_util_pmc_percent": pmc_mfma_util(a)[0],
+                                   "mfma_util_source": pmc_mfma_util(a)[1]}
         for extra, nbytes in (("lars_sgd_step", 7 * 33023552 * 4), ("ema_update", 3 * 32957888 * 4)):
             if extra in ms:
                 t = ms[extra] * 1e-3
