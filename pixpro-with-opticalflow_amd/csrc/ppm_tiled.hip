@@ -283,46 +283,50 @@ struct GramOp {
   const float* Rm;
   int m0, n0;
 };
+// Waves per Gram work-group.  Eight (a 4 x 2 grid of 16 x 32 blocks, one accumulator pair per wave and product) instead
+// of four (2 x 2 of 32 x 32): twice the waves per CU to hide the latency of a launch that is all prologues and epilogues.
+#ifndef TL_GW
+#define TL_GW 8
+#endif
+constexpr int GW = TL_GW, TBG = 64 * GW, GNI = GW == 8 ? 1 : 2, GNJ = 2;
+__device__ __forceinline__ int gram_wm(int wave) { return GW == 8 ? (wave >> 1) * 16 : (wave >> 1) * 32; }
+__device__ __forceinline__ int gram_wn(int wave) { return (wave & 1) * 32; }
 template <int NP>
-__device__ __forceinline__ void gram_core(f32x4 (&acc)[NP][2][2], const GramOp (&op)[NP], int C, int P, float* ring) {
-  constexpr int GKT = 32 / NP, SLAB = GKT * 64, PIECES = GKT / 16;      // k rows per slab; copies per wave and operand
+__device__ __forceinline__ void gram_core(f32x4 (&acc)[NP][GNI][GNJ], const GramOp (&op)[NP], int C, int P, float* ring) {
+  constexpr int GKT = 32 / NP, SLAB = GKT * 64;                         // k rows per slab
+  constexpr int OPP = GKT / 4;                                          // 1-KB pieces per operand and slab
+  constexpr int PIECES = NP * 2 * OPP / GW;                             // copies per wave and slab (2 or 4)
   const int t = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, lr = lane & 15, lq = lane >> 4;
-  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+  const int wm = gram_wm(wave), wn = gram_wn(wave);
   // 16 x 16 sub-tiles wholly beyond P (P = 196 = 12.25 sub-tiles per side) issue no MFMA (wave-uniform)
-  bool live[NP][2][2], full = true, any = false;
+  bool live[NP][GNI][GNJ], full = true, any = false;
 #pragma unroll
   for (int q = 0; q < NP; ++q)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < GNI; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < GNJ; ++j) {
         live[q][i][j] = (op[q].m0 + wm + 16 * i < P) && (op[q].n0 + wn + 16 * j < P);
         full = full && live[q][i][j];
         any = any || live[q][i][j];
       }
-  // this wave's pieces of a slab: k rows 4 PIECES wave .. + 4 PIECES - 1 of every operand
-  const float* srcL[NP][PIECES];
-  const float* srcR[NP][PIECES];
+  // The slab's NP * 2 operands x OPP pieces form one list (the buffer's layout: operand after operand, 256 floats per
+  // piece); this wave copies pieces PIECES * wave .. + PIECES - 1 of it.  Piece f: operand f / OPP (product f / (2 OPP), L or
+  // R by the parity), k rows 4 (f % OPP) .. + 3.
+  const float* src[PIECES];
 #pragma unroll
-  for (int q = 0; q < NP; ++q)
-#pragma unroll
-    for (int e = 0; e < PIECES; ++e) {
-      const int kk = 4 * PIECES * wave + 4 * e + lq, ch = lr ^ ((kk & 1) << 2);
-      srcL[q][e] = op[q].L + (size_t)kk * P + min(op[q].m0 + 4 * ch, P - 4);
-      srcR[q][e] = op[q].Rm + (size_t)kk * P + min(op[q].n0 + 4 * ch, P - 4);
-    }
+  for (int e = 0; e < PIECES; ++e) {
+    const int f = PIECES * wave + e, o = f / OPP, kk = 4 * (f % OPP) + lq, ch = lr ^ ((kk & 1) << 2);
+    const GramOp& g_ = op[NP == 1 ? 0 : (o >> 1)];
+    src[e] = ((o & 1) ? g_.Rm : g_.L) + (size_t)kk * P + min(((o & 1) ? g_.n0 : g_.m0) + 4 * ch, P - 4);
+  }
   const size_t slab_step = (size_t)GKT * P;
   auto issue = [&](int s) {
     float* buf = ring + (s % GNB) * NP * 2 * SLAB + 256 * PIECES * wave;
 #pragma unroll
-    for (int q = 0; q < NP; ++q)
-#pragma unroll
-      for (int e = 0; e < PIECES; ++e) {
-        dma16(srcL[q][e] + s * slab_step, buf + (2 * q) * SLAB + 256 * e);
-        dma16(srcR[q][e] + s * slab_step, buf + (2 * q + 1) * SLAB + 256 * e);
-      }
+    for (int e = 0; e < PIECES; ++e) dma16(src[e] + s * slab_step, buf + 256 * e);
   };
-  constexpr int PER = NP * 2 * PIECES;          // copies per wave and slab (4)
+  constexpr int PER = PIECES;                   // copies per wave and slab
   const int S = C / GKT;
   issue(0);
   if (S > 1 && GNB > 2) issue(1);
@@ -341,32 +345,30 @@ __device__ __forceinline__ void gram_core(f32x4 (&acc)[NP][2][2], const GramOp (
       for (int ks = 0; ks < GKT / 4; ++ks)
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
-          float av[2], bv[2];
+          float av[GNI], bv[GNJ];
 #pragma unroll
-          for (int i = 0; i < 2; ++i) {
-            av[i] = buf[(2 * q) * SLAB + (4 * ks + lq) * 64 + ((wm + 16 * i + lr) ^ sw)];
-            bv[i] = buf[(2 * q + 1) * SLAB + (4 * ks + lq) * 64 + ((wn + 16 * i + lr) ^ sw)];
-          }
+          for (int i = 0; i < GNI; ++i) av[i] = buf[(2 * q) * SLAB + (4 * ks + lq) * 64 + ((wm + 16 * i + lr) ^ sw)];
 #pragma unroll
-          for (int i = 0; i < 2; ++i)
+          for (int j = 0; j < GNJ; ++j) bv[j] = buf[(2 * q + 1) * SLAB + (4 * ks + lq) * 64 + ((wn + 16 * j + lr) ^ sw)];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[q][i][j] = mfma16(av[i], bv[j], acc[q][i][j]);
+          for (int i = 0; i < GNI; ++i)
+#pragma unroll
+            for (int j = 0; j < GNJ; ++j) acc[q][i][j] = mfma16(av[i], bv[j], acc[q][i][j]);
         }
     } else if (any) {
 #pragma unroll
       for (int ks = 0; ks < GKT / 4; ++ks)
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
-          float av[2], bv[2];
+          float av[GNI], bv[GNJ];
 #pragma unroll
-          for (int i = 0; i < 2; ++i) {
-            av[i] = buf[(2 * q) * SLAB + (4 * ks + lq) * 64 + ((wm + 16 * i + lr) ^ sw)];
-            bv[i] = buf[(2 * q + 1) * SLAB + (4 * ks + lq) * 64 + ((wn + 16 * i + lr) ^ sw)];
-          }
+          for (int i = 0; i < GNI; ++i) av[i] = buf[(2 * q) * SLAB + (4 * ks + lq) * 64 + ((wm + 16 * i + lr) ^ sw)];
 #pragma unroll
-          for (int i = 0; i < 2; ++i)
+          for (int j = 0; j < GNJ; ++j) bv[j] = buf[(2 * q + 1) * SLAB + (4 * ks + lq) * 64 + ((wn + 16 * j + lr) ^ sw)];
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+          for (int i = 0; i < GNI; ++i)
+#pragma unroll
+            for (int j = 0; j < GNJ; ++j)
               if (live[q][i][j]) acc[q][i][j] = mfma16(av[i], bv[j], acc[q][i][j]);
         }
     }
@@ -380,7 +382,7 @@ __device__ __forceinline__ void tl_finish(const float* __restrict__ lpart, const
                                           float* __restrict__ loss_n, float* __restrict__ loss, float* __restrict__ pos_num,
                                           float* __restrict__ pos_mean, int B, int N, int strips, int P, float* red) {
   float acc = 0.f;
-  for (int b = threadIdx.x; b < B; b += TB) {
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
     float s = 0.f;
     for (int k = 0; k < strips; ++k) s += lpart[(size_t)b * strips + k];
     const float cb = cnt_of(cnt, b);
@@ -395,7 +397,7 @@ __device__ __forceinline__ void tl_finish(const float* __restrict__ lpart, const
   __syncthreads();
   if (threadIdx.x == 0) {
     float tsum = 0.f;
-    for (int k = 0; k < TB / 64; ++k) tsum += red[k];
+    for (int k = 0; k < (int)blockDim.x / 64; ++k) tsum += red[k];
     *loss = -2.f * tsum / (float)N;
   }
   __syncthreads();
@@ -410,8 +412,8 @@ struct TlFin {                   // outputs of the loss reduction (MODE 1 of k_t
 __device__ __forceinline__ void tile_rows_out(const float* tile, float* __restrict__ dst, int r0, int c0, int P) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, c4 = lane & 15;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = 16 * wave + 4 * i + (lane >> 4);
+  for (int i = 0; i < 16 / GW; ++i) {
+    const int row = (64 / GW) * wave + 4 * i + (lane >> 4);
     if (r0 + row < P && c0 + 4 * c4 < P && (!(TL_ABL & 8) || tile[0] == 123.456f))
       *reinterpret_cast<float4*>(dst + (size_t)(r0 + row) * P + c0 + 4 * c4) =
           *reinterpret_cast<const float4*>(tile + row * EPS + 4 * c4);
@@ -419,7 +421,7 @@ __device__ __forceinline__ void tile_rows_out(const float* tile, float* __restri
 }
 
 template <int MODE>
-__global__ void __launch_bounds__(TB) k_tl_gram(Dirs D, TlWs w, int N, int C, int P, float p, float clampv, TlFin fin) {
+__global__ void __launch_bounds__(TBG) k_tl_gram(Dirs D, TlWs w, int N, int C, int P, float p, float clampv, TlFin fin) {
   __shared__ __attribute__((aligned(16))) float ring[GRING];      // slab ring, then the epilogue tiles
   static_assert(GRING >= 2 * 64 * EPS, "two epilogue tiles fit in the slab ring");
   // The loss reduction needs every strip of the launch before (k_tl_strip<0>) and nothing of this one: when gradients
@@ -427,7 +429,7 @@ __global__ void __launch_bounds__(TB) k_tl_gram(Dirs D, TlWs w, int N, int C, in
   if (MODE == 1 && blockIdx.x == 0)
     tl_finish(w.lpart, w.cnt, fin.loss_n, fin.loss, fin.pos_num, fin.pos_mean, fin.B, N, fin.strips, P, ring);
   const int t = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, lr = lane & 15, lq = lane >> 4;
-  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+  const int wm = gram_wm(wave), wn = gram_wn(wave);
   const size_t R = (size_t)C * P, Q = (size_t)P * P;
   const int nt = (P + 63) / 64;
   int b, rem;
@@ -445,22 +447,26 @@ __global__ void __launch_bounds__(TB) k_tl_gram(Dirs D, TlWs w, int N, int C, in
     // images leave through LDS - the accumulator layout (16 columns x 4 rows per lane group) stored 64-B pieces of four
     // rows per instruction, the mirror image 16-B pieces of 64 rows; now every store instruction writes four 256-B rows.
     const float* x = dd.x + (size_t)(b % N) * R;
-    f32x4 acc[1][2][2] = {{{z, z}, {z, z}}};
+    f32x4 acc[1][GNI][GNJ];
+#pragma unroll
+    for (int i = 0; i < GNI; ++i)
+#pragma unroll
+      for (int j = 0; j < GNJ; ++j) acc[0][i][j] = z;
     const GramOp op[1] = {{x, x, i0, j0}};
     gram_core<1>(acc, op, C, P, ring);
     const float* rx = w.rx + (size_t)b * P;
     const float* rv = w.rv + (size_t)b * P;
-    float a[2][2][4], d[2][2][4], rvm[2][4], rvn[2];
+    float a[GNI][GNJ][4], d[GNI][GNJ][4], rvm[GNI][4], rvn[GNJ];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) rvn[j] = rv[min(j0 + wn + 16 * j + lr, P - 1)];
+    for (int j = 0; j < GNJ; ++j) rvn[j] = rv[min(j0 + wn + 16 * j + lr, P - 1)];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < GNI; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) rvm[i][r] = rv[min(i0 + wm + 16 * i + 4 * lq + r, P - 1)];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < GNI; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < GNJ; ++j) {
         const float rxn = rx[min(j0 + wn + 16 * j + lr, P - 1)];
 #pragma unroll
         for (int r = 0; r < 4; ++r)
@@ -471,9 +477,9 @@ __global__ void __launch_bounds__(TB) k_tl_gram(Dirs D, TlWs w, int N, int C, in
 #pragma unroll
     for (int which = 0; which < 3; ++which) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < GNI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < GNJ; ++j) {
           float v[4], m[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -498,18 +504,28 @@ __global__ void __launch_bounds__(TB) k_tl_gram(Dirs D, TlWs w, int N, int C, in
     const float* v = dd.v + (size_t)(b % N) * R;
     const float* rv = w.rv + (size_t)b * P;
     const float* Dm = w.Dm + (size_t)b * Q;
-    f32x4 acc[2][2][2] = {{{z, z}, {z, z}}, {{z, z}, {z, z}}};
+    f32x4 acc[2][GNI][GNJ];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int i = 0; i < GNI; ++i)
+#pragma unroll
+        for (int j = 0; j < GNJ; ++j) acc[q][i][j] = z;
     if (ti != tj) {
       const GramOp op[2] = {{dY, v, i0, j0}, {dY, v, j0, i0}};
       gram_core<2>(acc, op, C, P, ring);
     } else {
-      f32x4 one[1][2][2] = {{{z, z}, {z, z}}};
+      f32x4 one[1][GNI][GNJ];
+#pragma unroll
+      for (int i = 0; i < GNI; ++i)
+#pragma unroll
+        for (int j = 0; j < GNJ; ++j) one[0][i][j] = z;
       const GramOp op[1] = {{dY, v, i0, j0}};
       gram_core<1>(one, op, C, P, ring);
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < GNI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[0][i][j] = one[0][i][j];
+        for (int j = 0; j < GNJ; ++j) acc[0][i][j] = one[0][i][j];
     }
     // dSs[i][j] = dS[i][j] + dS[j][i] with dS = rv[col] dA o D and D symmetric:  dSs[i][j] = D[i][j] (U1[i][j] + U2[j][i]),
     // U = rv[col] * dA staged in LDS per tile.  D is read row-major where the result is written (256-B rows); round 2
@@ -520,9 +536,9 @@ __global__ void __launch_bounds__(TB) k_tl_gram(Dirs D, TlWs w, int N, int C, in
       const int n0 = half ? i0 : j0;
       float* Lt = half ? T1 : T0;
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < GNI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < GNJ; ++j) {
           const int ln = wn + 16 * j + lr;
           const float rvn = rv[min(n0 + ln, P - 1)];
 #pragma unroll
@@ -533,7 +549,7 @@ __global__ void __launch_bounds__(TB) k_tl_gram(Dirs D, TlWs w, int N, int C, in
     const float* T2 = ti == tj ? T0 : T1;
     float* out = w.dSs + (size_t)b * Q;
     const float* rx = w.rx + (size_t)b * P;     // the 1/||x|| of dX^ = x^ dSs folded into the COLUMNS of the stored dSs
-    for (int e = t; e < 64 * 64; e += TB) {
+    for (int e = t; e < 64 * 64; e += TBG) {
       const int r = e >> 6, c = e & 63;
       if ((TL_ABL & 8) && T0[0] != 123.456f) continue;
       if (i0 + r < P && j0 + c < P) {
@@ -871,7 +887,7 @@ int run_tiled_c(const pixpro_problem& pb, const Dirs& D, const TlWs& w, float* l
   const TlFin fin{loss_n, loss, pos_num, pos_mean, B, nt};
   hipLaunchKernelGGL(k_tl_pre, dim3((6 + PREP_S) * B), dim3(TB), 0, st, pb, D, w);
   TL_CHECK("k_tl_pre");
-  hipLaunchKernelGGL(k_tl_gram<0>, dim3(nt * (nt + 1) / 2 * B), dim3(TB), 0, st, D, w, N, C, P, pb.p, pb.clamp, fin);
+  hipLaunchKernelGGL(k_tl_gram<0>, dim3(nt * (nt + 1) / 2 * B), dim3(TBG), 0, st, D, w, N, C, P, pb.p, pb.clamp, fin);
   TL_CHECK("k_tl_gram<0>");
   hipLaunchKernelGGL((k_tl_strip<MW, 0>), dim3(nt * B), dim3(TB), 0, st, pb, D, w, g0, (int)want_grad, nt);
   TL_CHECK("k_tl_strip<0>");
@@ -880,7 +896,7 @@ int run_tiled_c(const pixpro_problem& pb, const Dirs& D, const TlWs& w, float* l
     TL_CHECK("k_tl_finish");
     return PIXPRO_OK;
   }
-  hipLaunchKernelGGL(k_tl_gram<1>, dim3(nt * (nt + 1) / 2 * B), dim3(TB), 0, st, D, w, N, C, P, pb.p, pb.clamp, fin);
+  hipLaunchKernelGGL(k_tl_gram<1>, dim3(nt * (nt + 1) / 2 * B), dim3(TBG), 0, st, D, w, N, C, P, pb.p, pb.clamp, fin);
   TL_CHECK("k_tl_gram<1>");
   hipLaunchKernelGGL((k_tl_strip<MW, 1>), dim3(2 * nt * B), dim3(TB), 0, st, pb, D, w, g0, 1, nt);
   TL_CHECK("k_tl_strip<1>");
