@@ -579,29 +579,30 @@ __global__ void __launch_bounds__(TBG) k_tl_gram(Dirs D, TlWs w, int N, int C, i
 constexpr int SK = 16, SNB = 3;
 __device__ __forceinline__ int chunk_swz(int row) { return (-(row >> 2)) & 3; }
 
-template <int MW>
+template <int MW, int NWS>                    // MW 16-row tiles per wave, NWS waves: C = 16 MW NWS rows
 struct StripRing {                            // LDS carve of one strip work-group
-  static constexpr int A_FLOATS = 64 * MW * SK, B_FLOATS = 64 * SK, SLAB = A_FLOATS + B_FLOATS;
+  static constexpr int A_FLOATS = 16 * MW * NWS * SK, B_FLOATS = 64 * SK, SLAB = A_FLOATS + B_FLOATS;
 };
 
 // BMODE 0: B rows by DMA from Bsrc (row n0 + n of a [P][P] matrix);  BMODE 1: B generated by `gen(k0, slab B buffer)`.
-template <int MW, int BMODE, class Gen>
+template <int MW, int NWS, int BMODE, class Gen>
 __device__ __forceinline__ void strip_gemm(f32x4 (&acc)[MW][4], int P, int n0, int nlive, float* ring,
                                            const float* __restrict__ Asrc, const float* __restrict__ Bsrc,
                                            const float* __restrict__ zero16, Gen gen) {
-  using R = StripRing<MW>;
+  using R = StripRing<MW, NWS>;
   const int t = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, lr = lane & 15, lq = lane >> 4;
-  // DMA pieces of this wave: A piece e covers rows 64 e + 16 wave .. + 15 (lane -> row lane >> 2, position lane & 3);
-  // the one B piece covers B rows 16 wave .. + 15
+  // DMA pieces of this wave: A piece e covers rows 16 (NWS e + wave) .. + 15 (lane -> row lane >> 2, position lane & 3);
+  // the B slab has four pieces: wave w < 4 copies B rows 16 w .. + 15
   const float* pa[MW];
   int qa[MW];                                  // source k chunk of this lane (position ^ swizzle)
 #pragma unroll
   for (int e = 0; e < MW; ++e) {
-    const int row = 64 * e + 16 * wave + (lane >> 2);
+    const int row = 16 * (NWS * e + wave) + (lane >> 2);
     qa[e] = (lane & 3) ^ chunk_swz(row);
     pa[e] = Asrc + (size_t)row * P + 4 * qa[e];
   }
-  const int brow = 16 * wave + (lane >> 2), qb = (lane & 3) ^ chunk_swz(brow);
+  const bool hasb = BMODE == 0 && wave < 4;    // uniform
+  const int brow = 16 * (wave & 3) + (lane >> 2), qb = (lane & 3) ^ chunk_swz(brow);
   const float* pb = Bsrc + (size_t)min(n0 + brow, P - 1) * P + 4 * qb;   // rows beyond P: finite duplicates, never stored
   const int S = (P + SK - 1) / SK;
   auto issue = [&](int s) {
@@ -610,10 +611,9 @@ __device__ __forceinline__ void strip_gemm(f32x4 (&acc)[MW][4], int P, int n0, i
     const bool tail = k0 + SK > P;             // uniform: only the last slab of P = 196 has k chunks beyond P
 #pragma unroll
     for (int e = 0; e < MW; ++e)
-      dma16((tail && k0 + 4 * qa[e] >= P) ? zero16 : pa[e] + k0, buf + (64 * e + 16 * wave) * SK);
-    if (BMODE == 0) dma16((tail && k0 + 4 * qb >= P) ? zero16 : pb + k0, buf + R::A_FLOATS + 16 * wave * SK);
+      dma16((tail && k0 + 4 * qa[e] >= P) ? zero16 : pa[e] + k0, buf + 16 * (NWS * e + wave) * SK);
+    if (hasb) dma16((tail && k0 + 4 * qb >= P) ? zero16 : pb + k0, buf + R::A_FLOATS + 16 * (wave & 3) * SK);
   };
-  constexpr int PER = MW + (BMODE == 0 ? 1 : 0);       // copies per wave and slab
   issue(0);
   if (BMODE == 1) gen(0, ring + R::A_FLOATS);
   if (S > 1) {
@@ -633,8 +633,9 @@ __device__ __forceinline__ void strip_gemm(f32x4 (&acc)[MW][4], int P, int n0, i
     fb[nn] = R::A_FLOATS + row * SK + 4 * (lq ^ chunk_swz(row));
   }
   for (int s = 0; s < S; ++s) {
-    if (TL_ABL & 4) wait_vm<0>();
-    else if (s + 1 < S) wait_vm<PER>(); else wait_vm<0>();   // this wave's copies of slab s have landed
+    if ((TL_ABL & 4) || s + 1 >= S) wait_vm<0>();        // this wave's copies of slab s have landed ...
+    else if (hasb) wait_vm<MW + 1>();                     // ... (one slab's worth of copies may stay in flight:
+    else wait_vm<MW>();                                   //      MW pieces of A, and one of B in the waves that copy B)
     lds_barrier();                                      // ... everybody's; and slab s - 1 has been read by everybody
     if (s + 2 < S && !(TL_ABL & 4)) {
       issue(s + 2);
@@ -663,7 +664,8 @@ __device__ __forceinline__ void strip_gemm(f32x4 (&acc)[MW][4], int P, int n0, i
   lds_barrier();                                        // the ring may be refilled by the next product
 }
 
-// column sums over all C rows of v[nn] (this lane's columns 16*nn + lr): shuffles over lq, one LDS hop over the 4 waves
+// column sums over all C rows of v[nn] (this lane's columns 16*nn + lr): shuffles over lq, one LDS hop over the NWS waves
+template <int NWS>
 __device__ __forceinline__ void strip_colsum(float (&v)[4], float* part) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, lr = lane & 15;
 #pragma unroll
@@ -675,16 +677,23 @@ __device__ __forceinline__ void strip_colsum(float (&v)[4], float* part) {
   }
   __syncthreads();
 #pragma unroll
-  for (int nn = 0; nn < 4; ++nn) v[nn] = part[16 * nn + lr] + part[64 + 16 * nn + lr] + part[128 + 16 * nn + lr] + part[192 + 16 * nn + lr];
+  for (int nn = 0; nn < 4; ++nn) {
+    float s = part[16 * nn + lr];
+#pragma unroll
+    for (int k = 1; k < NWS; ++k) s += part[64 * k + 16 * nn + lr];
+    v[nn] = s;
+  }
   __syncthreads();
 }
 
 // MODE 0: forward + loss + dY (grid: B * strips).  MODE 1: dv / dx (grid: B * 2 strips; the item index selects).
-template <int MW, int MODE>
-__global__ void __launch_bounds__(TB) k_tl_strip(pixpro_problem pb, Dirs D, TlWs w, float g0, int want_grad, int ns) {
-  constexpr int C = 64 * MW;
-  __shared__ __attribute__((aligned(16))) float ring[SNB * StripRing<MW>::SLAB];      // 60 KB at C = 256
-  __shared__ float part[4 * 64];
+// MW 16-row tiles per wave, NWS waves per work-group (C = 16 MW NWS): 256 channels run as 8 waves x 32 rows - twice the
+// waves per CU of the 4 x 64 split (two work-groups per CU either way: the LDS ring), each with half the accumulators
+template <int MW, int MODE, int NWS>
+__global__ void __launch_bounds__(64 * NWS) k_tl_strip(pixpro_problem pb, Dirs D, TlWs w, float g0, int want_grad, int ns) {
+  constexpr int C = 16 * MW * NWS, TBS = 64 * NWS;
+  __shared__ __attribute__((aligned(16))) float ring[SNB * StripRing<MW, NWS>::SLAB];      // 60 KB at C = 256
+  __shared__ float part[NWS * 64];
   __shared__ unsigned long long bl[MODE == 0 ? 64 * (TL_MAXP / 64) : 1];             // the strip's mask bit rows
   __shared__ float rks[MODE == 0 ? TL_MAXP + SK : 1];                                // 1/||k_j||, zero beyond P
   const int N = pb.N, P = pb.H * pb.W, W64 = (P + 63) / 64;
@@ -708,8 +717,8 @@ __global__ void __launch_bounds__(TB) k_tl_strip(pixpro_problem pb, Dirs D, TlWs
   // columns x 4 rows per lane group) would load / store 64-B pieces of four rows per instruction - measured at 56 us of
   // the 141 us of k_tl_strip<1>; staged, every instruction moves four rows of up to 256 B, 16 B per lane.  Same wave
   // writes and reads its tile (LDS operations of a wave execute in order): no barrier.
-  constexpr int MC = MW >= 2 ? 2 : 1;           // 16-row tiles per staging pass
-  static_assert(SNB * StripRing<MW>::SLAB >= 4 * 16 * MC * EPS, "staging tiles fit in the ring");
+  constexpr int MC = (MW >= 2 && NWS == 4) ? 2 : 1;           // 16-row tiles per staging pass
+  static_assert(SNB * StripRing<MW, NWS>::SLAB >= NWS * 16 * MC * EPS, "staging tiles fit in the ring");
   float* scr = ring + wave * (16 * MC * EPS);
   auto rows_out = [&](float* __restrict__ dst, auto value) {      // value(m, nn, r) in accumulator layout -> rows of dst
 #pragma unroll
@@ -763,13 +772,13 @@ __global__ void __launch_bounds__(TB) k_tl_strip(pixpro_problem pb, Dirs D, TlWs
     // ---- Y = v^ A = v (diag(rv) A): the scale sits in the COLUMNS of the stored matrix AvT[n][k] = rv[k] A[n][k] (A is
     // symmetric), whose row n is column n of the operand: both operands stream k-contiguous, as they are
     // stage what the G product needs while the first copies travel: the strip's bit rows and 1/||k||
-    for (int e = t; e < 64 * W64; e += TB) {
+    for (int e = t; e < 64 * W64; e += TBS) {
       const int n = e / W64, wd = e - n * W64;
       bl[e] = n0 + n < P ? w.bits[((size_t)b * P + n0 + n) * W64 + wd] : 0ull;
     }
-    for (int e = t; e < P + SK; e += TB) rks[e] = e < P ? rk[e] : 0.f;
+    for (int e = t; e < P + SK; e += TBS) rks[e] = e < P ? rk[e] : 0.f;
     auto none = [](int, float*) {};
-    strip_gemm<MW, 0>(acc, P, n0, nlive, ring, v, Av, w.zero, none);
+    strip_gemm<MW, NWS, 0>(acc, P, n0, nlive, ring, v, Av, w.zero, none);
     float ry[4];
     {
       float s[4];
@@ -782,7 +791,7 @@ __global__ void __launch_bounds__(TB) k_tl_strip(pixpro_problem pb, Dirs D, TlWs
           for (int r = 0; r < 4; ++r) a = __builtin_fmaf(acc[m][nn][r], acc[m][nn][r], a);
         s[nn] = a;
       }
-      strip_colsum(s, part);
+      strip_colsum<NWS>(s, part);
 #pragma unroll
       for (int nn = 0; nn < 4; ++nn) ry[nn] = 1.f / fmaxf(sqrtf(s[nn]), 1e-12f);
     }
@@ -806,12 +815,13 @@ __global__ void __launch_bounds__(TB) k_tl_strip(pixpro_problem pb, Dirs D, TlWs
     // t >> 6) writes the four values of its k group as one 16-B store into the slab image (same swizzle as the copies).
     const int gn = t & 63, gq = t >> 6, gofs = gn * SK + 4 * (gq ^ chunk_swz(gn));
     auto gen = [&](int k0, float* Bbuf) {
+      if (NWS > 4 && t >= 256) return;                                 // 64 rows x 4 k groups: the first four waves
       const int k = k0 + 4 * gq;                                       // < P + SK: rks is zero there, the bits too
       const unsigned m4 = k < 64 * W64 ? (unsigned)(bl[gn * W64 + (k >> 6)] >> (k & 63)) & 15u : 0u;
       *reinterpret_cast<float4*>(Bbuf + gofs) = make_float4((m4 & 1u) ? rks[k] : 0.f, (m4 & 2u) ? rks[k + 1] : 0.f,
                                                             (m4 & 4u) ? rks[k + 2] : 0.f, (m4 & 8u) ? rks[k + 3] : 0.f);
     };
-    strip_gemm<MW, 1>(G, P, n0, nlive, ring, kk, nullptr, w.zero, gen);
+    strip_gemm<MW, NWS, 1>(G, P, n0, nlive, ring, kk, nullptr, w.zero, gen);
     // ---- <Y^, G> per column, loss partial, dY
     float tc[4];
 #pragma unroll
@@ -823,7 +833,7 @@ __global__ void __launch_bounds__(TB) k_tl_strip(pixpro_problem pb, Dirs D, TlWs
         for (int r = 0; r < 4; ++r) a = __builtin_fmaf(acc[m][nn][r], G[m][nn][r], a);
       tc[nn] = a;
     }
-    strip_colsum(tc, part);
+    strip_colsum<NWS>(tc, part);
     if (wave == 0) {
       float s = 0.f;
 #pragma unroll
@@ -847,7 +857,7 @@ __global__ void __launch_bounds__(TB) k_tl_strip(pixpro_problem pb, Dirs D, TlWs
     const float* Mat = (isx ? w.dSs : w.A) + (size_t)b * Q;
     const float* Aop = isx ? src : w.dY + (size_t)b * R;
     auto none = [](int, float*) {};
-    strip_gemm<MW, 0>(acc, P, n0, nlive, ring, Aop, Mat, w.zero, none);
+    strip_gemm<MW, NWS, 0>(acc, P, n0, nlive, ring, Aop, Mat, w.zero, none);
     float hat[MW][4][4];
     float s[4] = {0.f, 0.f, 0.f, 0.f}, rj[4];
 #pragma unroll
@@ -857,7 +867,7 @@ __global__ void __launch_bounds__(TB) k_tl_strip(pixpro_problem pb, Dirs D, TlWs
         hat[m][nn][r] = val * rj[nn];
         s[nn] = __builtin_fmaf(hat[m][nn][r], acc[m][nn][r], s[nn]);
       });
-    strip_colsum(s, part);
+    strip_colsum<NWS>(s, part);
     if (!(TL_ABL & 1) || s[0] == 123.456f)
       rows_out((isx ? dd.dx : dd.dv) + so,
                [&](int m, int nn, int r) { return (acc[m][nn][r] - hat[m][nn][r] * s[nn]) * rj[nn]; });
@@ -878,7 +888,7 @@ __global__ void __launch_bounds__(TB) k_tl_finish(const float* __restrict__ lpar
     if (int e = check_launch(what)) return e; \
   } while (0)
 
-template <int MW>
+template <int MW, int NWS>
 int run_tiled_c(const pixpro_problem& pb, const Dirs& D, const TlWs& w, float* loss_n, float* pos_num, float* pos_mean,
                 float* loss, hipStream_t st) {
   const int B = pb.N * pb.ndir, N = pb.N, C = pb.C, P = pb.H * pb.W, nt = (P + 63) / 64;
@@ -889,7 +899,7 @@ int run_tiled_c(const pixpro_problem& pb, const Dirs& D, const TlWs& w, float* l
   TL_CHECK("k_tl_pre");
   hipLaunchKernelGGL(k_tl_gram<0>, dim3(nt * (nt + 1) / 2 * B), dim3(TBG), 0, st, D, w, N, C, P, pb.p, pb.clamp, fin);
   TL_CHECK("k_tl_gram<0>");
-  hipLaunchKernelGGL((k_tl_strip<MW, 0>), dim3(nt * B), dim3(TB), 0, st, pb, D, w, g0, (int)want_grad, nt);
+  hipLaunchKernelGGL((k_tl_strip<MW, 0, NWS>), dim3(nt * B), dim3(64 * NWS), 0, st, pb, D, w, g0, (int)want_grad, nt);
   TL_CHECK("k_tl_strip<0>");
   if (!want_grad) {
     hipLaunchKernelGGL(k_tl_finish, dim3(1), dim3(TB), 0, st, w.lpart, w.cnt, loss_n, loss, pos_num, pos_mean, B, N, nt, P);
@@ -898,7 +908,7 @@ int run_tiled_c(const pixpro_problem& pb, const Dirs& D, const TlWs& w, float* l
   }
   hipLaunchKernelGGL(k_tl_gram<1>, dim3(nt * (nt + 1) / 2 * B), dim3(TBG), 0, st, D, w, N, C, P, pb.p, pb.clamp, fin);
   TL_CHECK("k_tl_gram<1>");
-  hipLaunchKernelGGL((k_tl_strip<MW, 1>), dim3(2 * nt * B), dim3(TB), 0, st, pb, D, w, g0, 1, nt);
+  hipLaunchKernelGGL((k_tl_strip<MW, 1, NWS>), dim3(2 * nt * B), dim3(64 * NWS), 0, st, pb, D, w, g0, 1, nt);
   TL_CHECK("k_tl_strip<1>");
   return PIXPRO_OK;
 }
@@ -922,9 +932,9 @@ int run_tiled(const pixpro_problem& pb, const pixpro_dir* dirs, float* loss_n, f
   for (int d = 0; d < PIXPRO_MAX_DIRS; ++d) D.d[d] = dirs[d < pb.ndir ? d : 0];
   const TlWs w = tl_carve(workspace, pb);
   switch (pb.C / 64) {
-    case 1: return run_tiled_c<1>(pb, D, w, loss_n, pos_num, pos_mean, loss, st);
-    case 2: return run_tiled_c<2>(pb, D, w, loss_n, pos_num, pos_mean, loss, st);
-    default: return run_tiled_c<4>(pb, D, w, loss_n, pos_num, pos_mean, loss, st);
+    case 1: return run_tiled_c<1, 4>(pb, D, w, loss_n, pos_num, pos_mean, loss, st);
+    case 2: return run_tiled_c<2, 4>(pb, D, w, loss_n, pos_num, pos_mean, loss, st);
+    default: return run_tiled_c<2, 8>(pb, D, w, loss_n, pos_num, pos_mean, loss, st);      // C = 256: 8 waves x 32 rows
   }
 }
 
