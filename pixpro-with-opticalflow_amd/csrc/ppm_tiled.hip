@@ -38,7 +38,7 @@ struct TlWs {                    // workspace carve (floats unless noted)
                                  // the strip products sit on the COLUMNS, row n of the stored matrix is operand column n
   float *dY;                     // [B][C][P]
   unsigned long long* bits;      // [B][P][W64]
-  float* zero;                   // 16 floats of zeros (written by k_tl_rnorms): what the copies fetch for k beyond P
+  float* zero;                   // 16 floats of zeros (written by k_tl_pre): what the copies fetch for k beyond P
 };
 
 inline size_t al256(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
@@ -98,7 +98,7 @@ __device__ __forceinline__ float cnt_of(const float* __restrict__ cnt, int b) {
 // ---- k_tl_pre: ONE launch for what depends on the inputs alone (round 2: two launches, 19 + 15 us; the norms are a
 // stream, the sample points a latency chain of flow taps - they overlap well) ----------------------------------------------
 //   work-groups [0, 6 B):        1 / max(||.||, 1e-12) of the columns of x, v, k: one work-group per (pair, tensor, column
-//                                half) - 16 B per lane along the rows (k_tl_rnorms read 4 B per lane in 64-column strips,
+//                                half) - 16 B per lane along the rows (round 2 read 4 B per lane in 64-column strips,
 //                                a quarter of them holding 4 of 196 columns), three equal streams per CU
 //   work-groups [6 B, 6 B + PREP_S B):  sample points (flow-displaced bin centres), positive-pair BIT rows, counts; every
 //                                work-group of a pair takes every PREP_S-th group of 4 rows
