@@ -73,7 +73,98 @@ def pmc_mfma_util(a):
             m = re.match(r"\s+MFMA utilisation \(derived\)\s+([\d.]+) %", line)
             if m and float(m.group(1)) > 0:
                 out[cur] = float(m.group(1))
+    # only the kernels the library still launches (a kept summary can outlive a kernel's template arguments)
+    live = _lib_bytes()
+    if live:
+        out = {k: v for k, v in out.items() if _mangled_fragment(k) in live}
     return (out or None), os.path.relpath(found[-1], ROOT)
+
+
+def pmc_attainable(a, measured_ms):
+    """The bound the single-launch PPM/loss kernel can reach on this chip, next to the fp32-MFMA roofline it is priced on: on
+    gfx950 v_mfma_f32_16x16x4_f32 shares the vector datapath (tools/mfma_valu_overlap.hip: the times of an MFMA wave and a
+    VALU wave on one SIMD ADD), so a SIMD needs at least  waves x (MFMA instructions x 32 cycles + other VALU instructions x
+    4 cycles)  per item, whatever the schedule.  Instruction counts per wave from the kept PMC summary (SQ_INSTS_VALU,
+    SQ_INSTS_VALU_MFMA_F32, SQ_WAVES at N = 256), 2 waves per SIMD (one 8-wave work-group per CU: LDS), 2.4 GHz."""
+    import glob
+    import re
+    if a.image_size != 224:
+        return None
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_ppm_fused_n256.txt")))
+    if not found:
+        return None
+    vals, cur = {}, None
+    for line in open(found[-1]):
+        if not line.startswith(" "):
+            cur = line.strip()
+        else:
+            m = re.match(r"\s+(\w+)\s+median\s+([\d.]+)", line)
+            if m and cur in ("ppm_nhwc_kernel", "ppm_fused_kernel"):
+                vals.setdefault(cur, {})[m.group(1)] = float(m.group(2))
+    for name in ("ppm_nhwc_kernel", "ppm_fused_kernel"):
+        v = vals.get(name)
+        if v and v.get("SQ_WAVES") and _mangled_fragment(name) in _lib_bytes():
+            mf = v["SQ_INSTS_VALU_MFMA_F32"] / v["SQ_WAVES"]
+            other = (v["SQ_INSTS_VALU"] - v["SQ_INSTS_VALU_MFMA_F32"]) / v["SQ_WAVES"]
+            items_per_wave = (2 * 256 * 8) / v["SQ_WAVES"]          # persistent kernels run several items per wave
+            cyc = 2 * (mf * 32 + other * 4) / items_per_wave        # per item and SIMD
+            rounds = -(-2 * a.batch // 256)                          # items per CU
+            floor_ms = rounds * cyc / 2.4e9 * 1e3
+            return {"kernel": name, "mfma_instructions_per_wave_and_item": round(mf / items_per_wave, 1),
+                    "other_valu_instructions_per_wave_and_item": round(other / items_per_wave, 1),
+                    "simd_cycles_per_item": int(cyc), "items_per_cu": rounds, "floor_ms_per_launch": round(floor_ms, 4),
+                    "frac_of_attainable": round(floor_ms / measured_ms, 4), "source": os.path.relpath(found[-1], ROOT),
+                    "note": "MFMA issue floor + non-overlappable VALU floor (DESIGN.md 4.1); the fp32-MFMA roofline fraction "
+                            "above prices the algorithmic flops only"}
+    return None
+
+
+_LIB_BYTES = None
+
+
+def _lib_bytes():
+    global _LIB_BYTES
+    if _LIB_BYTES is None:
+        try:
+            _LIB_BYTES = open(os.path.join(ROOT, "pixpro-with-opticalflow_amd", "lib", "libpixpro_hip.so"), "rb").read()
+        except OSError:
+            _LIB_BYTES = b""
+    return _LIB_BYTES
+
+
+def _mangled_fragment(kernel):
+    """'k_tl_strip<2, 0, 8>' -> b'10k_tl_stripILi2ELi0ELi8EE' (Itanium mangling of a function template with int arguments)."""
+    import re
+    m = re.match(r"(\w+)(?:<([^>]*)>)?", kernel)
+    name, targs = m.group(1), m.group(2)
+    frag = f"{len(name)}{name}"
+    if targs:
+        frag += "I" + "".join(f"Li{t.strip()}E" for t in targs.split(",")) + "E"
+    return frag.encode()
+
+
+VALU_ISSUE_PEAK = 1024 * 2.4e9 / 4      # wave64 instructions / s: 1024 SIMD16s, one wave64 VALU instruction per 4 cycles, 2.4 GHz
+
+
+def pmc_valu_instructions(a):
+    """Vector-ALU wave-instructions per launch of the dense nframe > 2 flow preparation (k_chain_up8 + the mask kernels) from
+    the committed PMC summary (SQ_INSTS_VALU, collected at N = 64, nframe = 6), scaled to the batch.  (count, source)."""
+    import glob
+    import re
+    if a.n_frames != 6:
+        return None, None
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_flow_nframe6_n64.txt")))
+    if not found:
+        return None, None
+    total, cur = 0.0, None
+    for line in open(found[-1]):
+        if not line.startswith(" "):
+            cur = line.strip()
+        else:
+            m = re.match(r"\s+SQ_INSTS_VALU\s+median\s+([\d.]+)", line)
+            if m and cur and (cur.startswith("k_chain") or cur.startswith("k_fbc")):
+                total += float(m.group(1))
+    return (total * a.batch / 64.0 if total else None), os.path.relpath(found[-1], ROOT)
 
 
 def cpu_model():
@@ -108,17 +199,32 @@ def parse():
                          "in host order, so with >1 rank the two branches would serialise at every layer anyway")
     ap.add_argument("--no-overlap-momentum", dest="overlap_momentum", action="store_const", const="off")
     ap.add_argument("--key-bn-group", action="store_true",
-                    help="with several ranks: the key encoder's SyncBN collectives on a process group of their own (second RCCL "
-                         "communicator) and the key branch on its second stream (--overlap-momentum auto then means on); "
-                         "unmeasured on hardware so far, off by default")
+                    help="EXPERIMENTAL, with several ranks: the key encoder's SyncBN collectives on a process group of their own "
+                         "(second RCCL communicator) and the key branch on its second stream (--overlap-momentum auto then "
+                         "means on).  Collectives of two communicators issued from two streams are not ordered against each "
+                         "other across ranks and may deadlock; never run over RCCL so far, off by default")
     ap.add_argument("--bn-view-batch", action="store_true",
                     help="both views of an encoder in one pass with per-view BatchNorm statistics: half the SyncBN collectives "
                          "(same statistics); unmeasured on more than one GPU, off by default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-configs", action="store_true",
+                    help="skip the two short legs for BASELINE configs[3] (nframe=6, N=64) and configs[4] (448^2, N=64) that the "
+                         "default one-GPU run appends under `extra_configs` (same process, same model)")
+    ap.add_argument("--extra-steps", type=int, default=10)
+    ap.add_argument("--extra-warmup", type=int, default=5)
+    ap.add_argument("--no-untuned-probe", action="store_true",
+                    help="skip the child process that times 3 steps with MIOpen's library heuristics (PIXPRO_NO_MIOPEN_DB=1) "
+                         "for `config.miopen_untuned_ms_per_step`")
+    ap.add_argument("--untuned-probe", action="store_true", help=argparse.SUPPRESS)   # the child's own mode
+    ap.add_argument("--no-syncbn-ab", action="store_true",
+                    help="with several ranks: skip the untimed A/B of the SyncBN exchange variants (`rccl.syncbn_ab`)")
+    ap.add_argument("--ab-key-bn-group", action="store_true",
+                    help="EXPERIMENTAL: add the --key-bn-group variant to the A/B.  Two RCCL communicators driven from two "
+                         "streams of one process may deadlock (never run over RCCL yet); off by default")
     ap.add_argument("--dry-launch", action="store_true",
                     help="launcher check without a GPU: start the ranks, form the process group over gloo on the CPU, run the "
                          "barrier / max-over-ranks timing reduction around an empty timed region, print the JSON line and stop")
-    ap.add_argument("--cpu-flow-images", type=int, default=8)
+    ap.add_argument("--cpu-flow-images", type=int, default=4, help="images per call of the CPU flow-preparation leg")
     ap.add_argument("--no-channels-last", dest="channels_last", action="store_false",
                     help="keep NCHW activations (default: channels_last, which MIOpen's fp32 implicit-GEMM kernels prefer)")
     return ap.parse_args()
@@ -226,8 +332,11 @@ class BnAudit:
 
 
 def cpu_baseline(a, args):
-    """The oracle on the host cores: file-mode flow preparation for `cpu_flow_images` images at 720x1280 and
-    PPM+loss forward+backward for one full batch; reported as hot-path images/s."""
+    """The oracle on the host cores, by BASELINE.md section 3's protocol: (ii) file-mode flow preparation for
+    `cpu_flow_images` images per call at 720x1280; (i) PPM + loss forward+backward
+    for one full batch with per-sample dense flow / mask tensors (what the reference's apply_optical_flow hands the model -
+    contiguous [N,2,Hf,Wf] / [N,Hf,Wf], not broadcast views); each 5 warm-up + 20 timed iterations, mean and min.  Reported
+    as hot-path images/s from the two means.  (iii), the config-1 step, is cpu_cfg1_step below.)"""
     from oracle import pixpro_oracle as O
     from contrast.synthetic import make_batch
     # the box exposes every host core but a 1-GPU job owns a share of them: use the affinity mask, capped
@@ -237,23 +346,27 @@ def cpu_baseline(a, args):
     data = make_batch(nf, image_size=8, n_frames=a.n_frames, device="cpu", seed=99)
     _, lo_f, lo_b = data[5]
     size = (720, 1280)
+    flow_warm, flow_reps, t_calls = 5, 20, []
     with O.aten_samplers():     # the ATen kernels the reference calls (bit-identical to the explicit restatement)
-        O.apply_optical_flow_file(lo_f[:1], lo_b[:1], size, True, 0.01, 0.5)
-        t0 = time.perf_counter()
-        ff, fb = O.apply_optical_flow_file(lo_f, lo_b, size, True, 0.01, 0.5)
-        t_flow = (time.perf_counter() - t0) / nf
+        for i in range(flow_warm + flow_reps):
+            t0 = time.perf_counter()
+            ff, fb = O.apply_optical_flow_file(lo_f, lo_b, size, True, 0.01, 0.5)
+            if i >= flow_warm:
+                t_calls.append((time.perf_counter() - t0) / nf)
+    t_flow, t_flow_min = sum(t_calls) / len(t_calls), min(t_calls)
     N, C, G = a.batch, 256, a.image_size // 32
     gen = torch.Generator().manual_seed(5)
     big = make_batch(N, image_size=8, n_frames=2, device="cpu", seed=98, with_flow=False)
     c1, c2 = big[2], big[3]
-    flow_f = ff[0][:1].expand(N, -1, -1, -1)
-    flow_b = fb[0][:1].expand(N, -1, -1, -1)
-    mask_f = ff[2][:1].expand(N, -1, -1)
-    mask_b = fb[2][:1].expand(N, -1, -1)
+    rep = (N + nf - 1) // nf        # every sample owns its maps (the nf prepared ones, tiled): N x 7.4 MB per direction
+    flow_f = ff[0].repeat(rep, 1, 1, 1)[:N].contiguous()
+    flow_b = fb[0].repeat(rep, 1, 1, 1)[:N].contiguous()
+    mask_f = ff[2].repeat(rep, 1, 1)[:N].contiguous()
+    mask_b = fb[2].repeat(rep, 1, 1)[:N].contiguous()
     xs = [torch.randn(N, C, G, G, generator=gen).requires_grad_(True) for _ in range(4)]
     ks = [torch.randn(N, C, G, G, generator=gen) for _ in range(2)]
-    reps, t_ppm = 0, 0.0
-    while t_ppm < 3.0 and reps < 20:
+    ppm_warm, ppm_reps, t_reps = 5, 20, []
+    for i in range(ppm_warm + ppm_reps):
         t0 = time.perf_counter()
         A = [c1, [flow_f, size, mask_f]]
         B = [c2, [flow_b, size, mask_b]]
@@ -261,15 +374,18 @@ def cpu_baseline(a, args):
             l1 = O.ppm_loss(xs[0], xs[1], ks[1], A, B, 2.0, 0.0, 0.7, True)[0]
             l2 = O.ppm_loss(xs[2], xs[3], ks[0], B, A, 2.0, 0.0, 0.7, True)[0]
         (l1 + l2).backward()
-        t_ppm += time.perf_counter() - t0
-        reps += 1
-    t_ppm = t_ppm / reps / N
+        if i >= ppm_warm:
+            t_reps.append((time.perf_counter() - t0) / N)
+    t_ppm, t_ppm_min = sum(t_reps) / len(t_reps), min(t_reps)
     return {"value": round(1.0 / (t_flow + t_ppm), 2), "unit": "images/s (hot path only: flow prep + PPM/loss fwd+bwd)",
             "cores": threads, "cpu_model": cpu_model(), "kind": "port",
             "sample": f"oracle/pixpro_oracle.py (ATen samplers), torch-CPU fp32, {threads} threads: flow prep nframe={a.n_frames} "
-                      f"720x1280 on {nf} images ({t_flow * 1e3:.1f} ms/img) + PPM/loss fwd+bwd on {N} images x{reps} "
-                      f"({t_ppm * 1e3:.3f} ms/img); encoders excluded",
-            "flow_ms_per_image": round(t_flow * 1e3, 3), "ppm_ms_per_image": round(t_ppm * 1e3, 4)}
+                      f"720x1280 on {nf} images, {flow_warm} warm-up + {flow_reps} timed calls (mean {t_flow * 1e3:.1f}, min "
+                      f"{t_flow_min * 1e3:.1f} ms/img) + PPM/loss fwd+bwd on {N} images with per-sample dense maps, {ppm_warm} "
+                      f"warm-up + {ppm_reps} timed (mean {t_ppm * 1e3:.3f}, min {t_ppm_min * 1e3:.3f} ms/img); encoders excluded",
+            "flow_ms_per_image": round(t_flow * 1e3, 3), "flow_ms_per_image_min": round(t_flow_min * 1e3, 3),
+            "ppm_ms_per_image": round(t_ppm * 1e3, 4), "ppm_ms_per_image_min": round(t_ppm_min * 1e3, 4),
+            "protocol": {"flow": [flow_warm, flow_reps], "ppm": [ppm_warm, ppm_reps]}}
 
 
 def cpu_cfg1_step():
@@ -312,17 +428,118 @@ def cpu_cfg1_step():
         d = make_batch(8, image_size=64, n_frames=2, frame_hw=(180, 320), device="cpu", seed=7, with_flow=False)
         zf = torch.zeros(8, 2, 180, 320)
         c1, c2 = [d[2], [zf, (180, 320), None]], [d[3], [zf, (180, 320), None]]
-        ts = []
-        for i in range(4):
+        ts, warm, reps = [], 5, 20           # >= 5 warm-up + >= 20 timed iterations
+        for i in range(warm + reps):
             t0 = time.perf_counter()
             loss, _ = model(d[0], d[1], c1, c2)
             opt.zero_grad()
             loss.backward()
             opt.step()
-            ts.append(time.perf_counter() - t0)
-        return 8.0 / (sum(ts[1:]) / len(ts[1:]))
+            if i >= warm:
+                ts.append(time.perf_counter() - t0)
+        return 8.0 / (sum(ts) / len(ts))
     finally:
         ops.ppm_loss, pixpro_mod.ema_update = saved
+
+
+def hot_kernel_lines(a, ms, ms_single=None, ms_lazy=None, bn=None):
+    """`hot_kernels` of a JSON line from the HIP-event clocks of the C-ABI calls (KernelClock.mean_ms): algorithmic bytes /
+    flops per launch over the measured duration, against the HBM / fp32-MFMA peaks.  `a` carries batch,
+    image_size, n_frames, arch, overlap_momentum of the configuration that was timed."""
+    P = (a.image_size // 32) ** 2
+    C = 256
+    A = 720 * 1280 * 4
+    F1 = a.n_frames - 1
+    # algorithmic bytes per image (SURVEY.md §8d): dense flow prep B_flow; PPM+loss 10*C*P*4; flops 24*C*P^2
+    b_flow = (2 * F1 * 2 * A / 64 + 2 * F1 * 2 * A * 2 + 4 * A + A / 2)
+    b_ppm, f_ppm = 10 * C * P * 4, 24 * C * P * P
+    kernels = {}
+    if "flow_prepare" in ms:
+        t = ms["flow_prepare"] * 1e-3
+        # SURVEY 8d gives two per-image byte counts for the dense flow preparation: B_flow, what the reference's
+        # unfused pipeline moves (up-sampled maps written and read back), and the fused lower bound (read the
+        # 1/8-resolution maps once, write flows + masks once).  The launches here ARE fused, so the roofline is priced
+        # on the lower bound - what they must move; the B_flow ratio is kept beside it (it exceeds 1 for a fused
+        # kernel by construction and says nothing about kernel quality).
+        b_fused = (F1 * A / 16 + 4.5 * A)
+        kernels["flow_prepare"] = {"bound": "hbm", "achieved": round(b_fused * a.batch / t / 1e9, 1), "peak": HBM_PEAK / 1e9,
+                                   "unit": "GB/s", "frac": round(b_fused * a.batch / t / HBM_PEAK, 4),
+                                   "traffic": pmc_traffic("flow_prepare", a)[0],
+                                   "traffic_source": pmc_traffic("flow_prepare", a)[1],
+                                   "ms_per_launch": round(ms["flow_prepare"], 4),
+                                   "algorithmic_bytes_per_launch": int(b_fused * a.batch),
+                                   "unfused_pipeline_bytes_per_launch": int(b_flow * a.batch),
+                                   "ratio_to_unfused_pipeline_at_peak": round(b_flow * a.batch / t / HBM_PEAK, 4),
+                                   "note": "algorithmic bytes = SURVEY 8d fused lower bound ((F-1)A/16 + 4.5A per image: "
+                                           "low-res maps in, dense flows + masks out); SURVEY's B_flow prices the "
+                                           "reference's unfused pipeline and is reported as "
+                                           "ratio_to_unfused_pipeline_at_peak; DESIGN.md 4.3"}
+        vi, vsrc = pmc_valu_instructions(a)
+        if vi:
+            # the chain of nframe > 2 is bound by vector-ALU ISSUE, not by HBM (bit-exact tap arithmetic, ~136 instructions
+            # per pixel and chain step): price it on that as well, so that the HBM fraction does not stand in for quality
+            kernels["flow_prepare"]["valu_issue"] = {
+                "bound": "valu_issue", "wave_instructions_per_launch": int(vi), "source": vsrc,
+                "peak_wave_instructions_per_s": VALU_ISSUE_PEAK, "achieved": round(vi / t, 1),
+                "frac": round(vi / t / VALU_ISSUE_PEAK, 4),
+                "note": "SQ_INSTS_VALU of the launch's kernels (kept PMC summary, scaled to the batch) over the measured "
+                        "duration, against 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction; tools/ubench/valu_rate.hip "
+                        "measures 2.8 (mul/add) to 5 (fma) cycles per instruction on this chip, so ~0.8-0.9 is the practical ceiling"}
+    if "ppm_loss" in ms:
+        t = ms["ppm_loss"] * 1e-3
+        util, util_src = pmc_mfma_util(a)
+        kernels["ppm_loss"] = {"bound": "mfma", "achieved": round(f_ppm * a.batch / t / 1e12, 3),
+                               "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
+                               "frac": round(f_ppm * a.batch / t / MFMA_F32_PEAK, 4),
+                               "traffic": pmc_traffic("ppm_loss", a)[0],
+                               "traffic_source": pmc_traffic("ppm_loss", a)[1],
+                               "ms_per_launch": round(ms["ppm_loss"], 4),
+                               "algorithmic_flops_per_launch": int(f_ppm * a.batch),
+                               "hbm_frac": round(b_ppm * a.batch / t / HBM_PEAK, 4),
+                               "mfma_util_pmc_percent": util, "mfma_util_source": util_src}
+        att = pmc_attainable(a, ms["ppm_loss"])
+        if att:
+            kernels["ppm_loss"]["attainable"] = att
+    for extra, nbytes in (("lars_sgd_step", 7 * 33023552 * 4), ("ema_update", 3 * 32957888 * 4)):
+        if extra in ms:
+            t = ms[extra] * 1e-3
+            kernels[extra] = {"bound": "hbm", "achieved": round(nbytes / t / 1e9, 1), "peak": HBM_PEAK / 1e9,
+                              "unit": "GB/s", "frac": round(nbytes / t / HBM_PEAK, 4), "traffic": None,
+                              "ms_per_launch": round(ms[extra], 4), "algorithmic_bytes_per_launch": nbytes}
+            if extra == "ema_update" and a.overlap_momentum and ms_single and extra in ms_single:
+                # in the timed steps this launch shares the GPU with the online branch (second stream): the figure
+                # that prices the kernel is the single-stream audit step's
+                t1 = ms_single[extra] * 1e-3
+                kernels[extra].update({"achieved": round(nbytes / t1 / 1e9, 1), "frac": round(nbytes / t1 / HBM_PEAK, 4),
+                                       "ms_per_launch": round(ms_single[extra], 4),
+                                       "ms_per_launch_overlapped": round(ms[extra], 4),
+                                       "note": "achieved/frac from the single-stream audit step; in the timed steps the "
+                                               "launch runs on the second stream next to the online branch"})
+    if ms_lazy and "ppm_loss" in ms_lazy:
+        t = ms_lazy["ppm_loss"] * 1e-3
+        kernels["ppm_loss_lazy"] = {"bound": "mfma", "achieved": round(f_ppm * a.batch / t / 1e12, 3),
+                                    "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
+                                    "frac": round(f_ppm * a.batch / t / MFMA_F32_PEAK, 4), "traffic": None,
+                                    "ms_per_launch": round(ms_lazy["ppm_loss"], 4),
+                                    "algorithmic_flops_per_launch": int(f_ppm * a.batch),
+                                    "note": "sparse variant (--lazy-flow), one extra untimed step: no flow_prepare launch, "
+                                            "flow chain + consistency mask evaluated at the loss sample points inside "
+                                            "this launch; never mixed with the dense figures"}
+    if bn:
+        n_l = sum(v[0] for v in bn.values())
+        t_ms = sum(v[1] for v in bn.values())
+        nb = sum(v[2] for v in bn.values())
+        kernels["batch_norm"] = {"bound": "hbm", "achieved": round(nb / (t_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK / 1e9,
+                                 "unit": "GB/s", "frac": round(nb / (t_ms * 1e-3) / HBM_PEAK, 4),
+                                 "traffic": pmc_traffic("batch_norm", a)[0] if a.arch == "resnet50" else None,
+                                 "traffic_source": pmc_traffic("batch_norm", a)[1] if a.arch == "resnet50" else None,
+                                 "ms_per_step": round(t_ms, 3), "launch_pairs_per_step": n_l,
+                                 "algorithmic_bytes_per_step": int(nb),
+                                 "by_call": {k: {"n": v[0], "ms": round(v[1], 3),
+                                                 "GB/s": round(v[2] / (v[1] * 1e-3) / 1e9, 1)} for k, v in bn.items()},
+                                 "note": "fused (Sync)BatchNorm + ReLU + residual add, one audited step with both branches "
+                                         "on one stream; bytes = tensor passes x rows x C x 4 (DESIGN.md 4.7)"}
+    return kernels
 
 
 def _free_port():
@@ -406,6 +623,126 @@ def dry_launch(a, world, rank):
         dist.destroy_process_group()
 
 
+def timed_steps(step_fn, steps, world, dev):
+    """EXACTLY `steps` calls of step_fn between barrier + synchronize pairs; the MAX over ranks of the wall time."""
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = None
+    for _ in range(steps):
+        out = step_fn()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    return elapsed, out
+
+
+def extra_config_leg(a, name, image_size, n_frames, batch, model, optimizer, scheduler, args, clock, dev, rank):
+    """One short leg of another BASELINE config in the same process and on the same model (the encoders are
+    size-agnostic): `--extra-warmup` untimed + `--extra-steps` timed steps, the same HIP-event clocks around the hot calls."""
+    import copy
+    import main_pretrain
+    from contrast.synthetic import SyntheticLoader
+    b = copy.copy(a)
+    b.image_size, b.n_frames, b.batch = image_size, n_frames, batch
+    loader = SyntheticLoader(a.extra_steps + a.extra_warmup, batch, pool=2, image_size=image_size, n_frames=n_frames,
+                             frame_hw=(720, 1280), device=dev, seed=4321 + rank, channels_last=a.channels_last)
+    it = iter(loader)
+    for _ in range(a.extra_warmup):
+        main_pretrain.train_step(model, optimizer, scheduler, next(it), args)
+    torch.cuda.synchronize()
+    clock.reset()
+    elapsed, _ = timed_steps(lambda: main_pretrain.train_step(model, optimizer, scheduler, next(it), args), a.extra_steps, 1, dev)
+    ms = clock.mean_ms()
+    # the sparse variant beside the dense one (never mixed): one more untimed step
+    clock.reset()
+    args.lazy_flow = True
+    main_pretrain.train_step(model, optimizer, scheduler, next(iter(loader)), args)
+    torch.cuda.synchronize()
+    args.lazy_flow = False
+    ms_lazy = clock.mean_ms()
+    del loader, it
+    torch.cuda.empty_cache()
+    note(rank, f"extra config {name}: {batch * a.extra_steps / elapsed:.1f} images/s; hot kernels (ms): {ms}")
+    return {"workload": f"{a.arch} PixPro+optical-flow pre-train step, {image_size}x{image_size} crops, nframe={n_frames}, "
+                        f"per-GPU batch {batch}, otherwise as config.workload",
+            "baseline_config": name, "value": round(batch * a.extra_steps / elapsed, 2), "unit": "images/s",
+            "ms_per_step": round(elapsed / a.extra_steps * 1e3, 3), "steps": a.extra_steps, "warmup": a.extra_warmup,
+            "hot_kernels": hot_kernel_lines(b, ms, None, ms_lazy, None)}
+
+
+def untuned_probe(a):
+    """config.miopen_untuned_ms_per_step: the same step with MIOpen's library heuristics instead of the shipped find-db, in
+    a child process (MIOpen reads its db paths once per process): PIXPRO_NO_MIOPEN_DB=1, 2 warm-up + 3 timed steps."""
+    import subprocess
+    env = dict(os.environ, PIXPRO_NO_MIOPEN_DB="1")
+    for k in ("MIOPEN_USER_DB_PATH", "MIOPEN_CUSTOM_CACHE_DIR"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.abspath(__file__), "--untuned-probe", "--steps", "3", "--warmup", "2", "--batch", str(a.batch),
+           "--image-size", str(a.image_size), "--n-frames", str(a.n_frames), "--arch", a.arch, "--no-cpu-baseline"]
+    if not a.channels_last:
+        cmd.append("--no-channels-last")
+    if not a.fused_bn:
+        cmd.append("--no-fused-bn")
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+        return json.loads(line)["untuned_ms_per_step"]
+    except Exception as exc:      # informative only
+        return f"not measured: {exc!r}"
+
+
+def syncbn_ab(a, model, optimizer, scheduler, args, loader, world, dev, rank):
+    """N > 1 only, after the timed region: the SyncBN exchange variants on the same model, 3 warm-up + 5 timed steps each
+    (max over ranks), so that the first run on real xGMI says which setting the next one should use.
+      default        one collective per layer, view and direction (324 per step), both branches on one stream
+      bn_view_batch  both views of an encoder in one pass, per-view statistics: 162 collectives per step
+      key_bn_group   (only with --ab-key-bn-group: EXPERIMENTAL, may deadlock over RCCL) the key encoder's collectives on a
+                     second communicator, the key branch on its second stream"""
+    import main_pretrain
+    inner = model.module if hasattr(model, "module") else model
+    saved = (inner.view_batch, inner.overlap_momentum)
+    out = {}
+
+    def run(name):
+        it = iter(loader)
+        for _ in range(3):
+            main_pretrain.train_step(model, optimizer, scheduler, next(it), args)
+        el, _ = timed_steps(lambda: main_pretrain.train_step(model, optimizer, scheduler, next(it), args), 5, world, dev)
+        out[name] = round(el / 5 * 1e3, 3)
+        note(rank, f"syncbn A/B {name}: {out[name]} ms/step")
+
+    inner.view_batch, inner.overlap_momentum = False, False
+    run("default")
+    if a.fused_bn:
+        inner.view_batch = True
+        run("bn_view_batch")
+        inner.view_batch = False
+    if a.ab_key_bn_group and a.fused_bn:
+        from contrast.sync_bn import FusedSyncBatchNorm
+        grp = dist.new_group()
+        mods = [m for enc in (inner.encoder_k, inner.projector_k) for m in enc.modules() if isinstance(m, FusedSyncBatchNorm)]
+        prev = [m.process_group for m in mods]
+        for m in mods:
+            m.process_group = grp
+        inner.overlap_momentum = True
+        run("key_bn_group+second_stream")
+        for m, g in zip(mods, prev):
+            m.process_group = g
+    inner.view_batch, inner.overlap_momentum = saved
+    out["note"] = ("ms per step, 3 warm-up + 5 timed steps each after the headline region (never part of `value`); the headline "
+                   "ran with " + ("bn_view_batch" if a.bn_view_batch else "default")
+                   + (" + key_bn_group" if a.key_bn_group else ""))
+    return out
+
+
 def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -484,24 +821,18 @@ def main():
     miopen_note = miopen_status()
     note(rank, f"MIOpen: {miopen_note}")
     clock.reset()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        loss, _, _ = main_pretrain.train_step(model, optimizer, scheduler, next(it), args)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
+    elapsed, (loss, _, _) = timed_steps(lambda: main_pretrain.train_step(model, optimizer, scheduler, next(it), args),
+                                        a.steps, world, dev)
     final_loss = loss.item()
     ms = clock.mean_ms()
     note(rank, f"timed {a.steps} steps in {elapsed:.2f} s; hot kernels (ms): {ms}")
+    if a.untuned_probe:           # child of untuned_probe(): only the step time is wanted
+        if rank == 0:
+            print(json.dumps({"untuned_ms_per_step": round(elapsed / a.steps * 1e3, 3), "miopen": miopen_note}), flush=True)
+        return
+    ab = None
+    if world > 1 and not a.no_syncbn_ab:
+        ab = syncbn_ab(a, model, optimizer, scheduler, args, loader, world, dev, rank)
     # Two extra, untimed steps (rank 0, one rank only) for figures the timed region cannot give cleanly:
     #  (1) everything on ONE stream: with the key branch on its second stream an event pair spans shared-GPU time, so the
     #      per-call clocks of the BN kernels and of the EMA launch are only meaningful here (reproduces the rocprof sums);
@@ -530,86 +861,23 @@ def main():
         inner.overlap_momentum = saved_overlap
         note(rank, f"single-stream audit step (ms): {ms_single}; lazy-flow step (ms): {ms_lazy}")
 
+    extra = None
+    if rank == 0 and world == 1 and not a.no_extra_configs and (a.image_size, a.n_frames) == (224, 2) and a.arch == "resnet50":
+        extra = {}
+        for name, size_, nf_, nb_ in (("configs[3] per-GPU share: nframe=6, global batch 512 over 8 GPUs", 224, 6, 64),
+                                      ("configs[4] per-GPU share: 448x448 crops (14x14 grid), N=64", 448, 2, 64)):
+            key = f"nframe{nf_}_n{nb_}" if nf_ != 2 else f"crop{size_}_n{nb_}"
+            try:
+                extra[key] = extra_config_leg(a, name, size_, nf_, nb_, model, optimizer, scheduler, args, clock, dev, rank)
+            except Exception as exc:      # never lose the headline line to an extra leg
+                extra[key] = {"error": repr(exc)}
+                torch.cuda.synchronize()
+    untuned = None
+    if rank == 0 and world == 1 and not a.no_untuned_probe and not a.no_cpu_baseline:
+        note(rank, "timing 3 steps with MIOpen's library heuristics in a child process")
+        untuned = untuned_probe(a)
     if rank == 0:
-        P = (a.image_size // 32) ** 2
-        C = 256
-        A = 720 * 1280 * 4
-        F1 = a.n_frames - 1
-        # algorithmic bytes per image: dense flow prep B_flow; PPM+loss 10*C*P*4; flops 24*C*P^2
-        b_flow = (2 * F1 * 2 * A / 64 + 2 * F1 * 2 * A * 2 + 4 * A + A / 2)
-        b_ppm, f_ppm = 10 * C * P * 4, 24 * C * P * P
-        kernels = {}
-        if "flow_prepare" in ms:
-            t = ms["flow_prepare"] * 1e-3
-            # SURVEY 8d gives two per-image byte counts for the dense flow preparation: B_flow, what the reference's
-            # unfused pipeline moves (up-sampled maps written and read back), and the fused lower bound (read the
-            # 1/8-resolution maps once, write flows + masks once).  The launches here ARE fused, so the roofline is priced
-            # on the lower bound - what they must move; the B_flow ratio is kept beside it (it exceeds 1 for a fused
-            # kernel by construction and says nothing about kernel quality).
-            b_fused = (F1 * A / 16 + 4.5 * A)
-            kernels["flow_prepare"] = {"bound": "hbm", "achieved": round(b_fused * a.batch / t / 1e9, 1), "peak": HBM_PEAK / 1e9,
-                                       "unit": "GB/s", "frac": round(b_fused * a.batch / t / HBM_PEAK, 4),
-                                       "traffic": pmc_traffic("flow_prepare", a)[0],
-                                       "traffic_source": pmc_traffic("flow_prepare", a)[1],
-                                       "ms_per_launch": round(ms["flow_prepare"], 4),
-                                       "algorithmic_bytes_per_launch": int(b_fused * a.batch),
-                                       "unfused_pipeline_bytes_per_launch": int(b_flow * a.batch),
-                                       "ratio_to_unfused_pipeline_at_peak": round(b_flow * a.batch / t / HBM_PEAK, 4),
-                                       "note": "algorithmic bytes = SURVEY 8d fused lower bound ((F-1)A/16 + 4.5A per image: "
-                                               "low-res maps in, dense flows + masks out); SURVEY's B_flow prices the "
-                                               "reference's unfused pipeline and is reported as "
-                                               "ratio_to_unfused_pipeline_at_peak; DESIGN.md 4.3"}
-        if "ppm_loss" in ms:
-            t = ms["ppm_loss"] * 1e-3
-            kernels["ppm_loss"] = {"bound": "mfma", "achieved": round(f_ppm * a.batch / t / 1e12, 3),
-                                   "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
-                                   "frac": round(f_ppm * a.batch / t / MFMA_F32_PEAK, 4),
-                                   "traffic": pmc_traffic("ppm_loss", a)[0],
-                                   "traffic_source": pmc_traffic("ppm_loss", a)[1],
-                                   "ms_per_launch": round(ms["ppm_loss"], 4),
-                                   "algorithmic_flops_per_launch": int(f_ppm * a.batch),
-                                   "hbm_frac": round(b_ppm * a.batch / t / HBM_PEAK, 4),
-                                   "mfma_util_pmc_percent": pmc_mfma_util(a)[0],
-                                   "mfma_util_source": pmc_mfma_util(a)[1]}
-        for extra, nbytes in (("lars_sgd_step", 7 * 33023552 * 4), ("ema_update", 3 * 32957888 * 4)):
-            if extra in ms:
-                t = ms[extra] * 1e-3
-                kernels[extra] = {"bound": "hbm", "achieved": round(nbytes / t / 1e9, 1), "peak": HBM_PEAK / 1e9,
-                                  "unit": "GB/s", "frac": round(nbytes / t / HBM_PEAK, 4), "traffic": None,
-                                  "ms_per_launch": round(ms[extra], 4), "algorithmic_bytes_per_launch": nbytes}
-                if extra == "ema_update" and a.overlap_momentum and ms_single and extra in ms_single:
-                    # in the timed steps this launch shares the GPU with the online branch (second stream): the figure
-                    # that prices the kernel is the single-stream audit step's
-                    t1 = ms_single[extra] * 1e-3
-                    kernels[extra].update({"achieved": round(nbytes / t1 / 1e9, 1), "frac": round(nbytes / t1 / HBM_PEAK, 4),
-                                           "ms_per_launch": round(ms_single[extra], 4),
-                                           "ms_per_launch_overlapped": round(ms[extra], 4),
-                                           "note": "achieved/frac from the single-stream audit step; in the timed steps the "
-                                                   "launch runs on the second stream next to the online branch"})
-        if ms_lazy and "ppm_loss" in ms_lazy:
-            t = ms_lazy["ppm_loss"] * 1e-3
-            kernels["ppm_loss_lazy"] = {"bound": "mfma", "achieved": round(f_ppm * a.batch / t / 1e12, 3),
-                                        "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
-                                        "frac": round(f_ppm * a.batch / t / MFMA_F32_PEAK, 4), "traffic": None,
-                                        "ms_per_launch": round(ms_lazy["ppm_loss"], 4),
-                                        "algorithmic_flops_per_launch": int(f_ppm * a.batch),
-                                        "note": "sparse variant (--lazy-flow), one extra untimed step: no flow_prepare launch, "
-                                                "flow chain + consistency mask evaluated at the loss sample points inside "
-                                                "this launch; never mixed with the dense figures"}
-        if bn:
-            n_l = sum(v[0] for v in bn.values())
-            t_ms = sum(v[1] for v in bn.values())
-            nb = sum(v[2] for v in bn.values())
-            kernels["batch_norm"] = {"bound": "hbm", "achieved": round(nb / (t_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK / 1e9,
-                                     "unit": "GB/s", "frac": round(nb / (t_ms * 1e-3) / HBM_PEAK, 4),
-                                     "traffic": pmc_traffic("batch_norm", a)[0] if a.arch == "resnet50" else None,
-                                     "traffic_source": pmc_traffic("batch_norm", a)[1] if a.arch == "resnet50" else None,
-                                     "ms_per_step": round(t_ms, 3), "launch_pairs_per_step": n_l,
-                                     "algorithmic_bytes_per_step": int(nb),
-                                     "by_call": {k: {"n": v[0], "ms": round(v[1], 3),
-                                                     "GB/s": round(v[2] / (v[1] * 1e-3) / 1e9, 1)} for k, v in bn.items()},
-                                     "note": "fused (Sync)BatchNorm + ReLU + residual add, one audited step with both branches "
-                                             "on one stream; bytes = tensor passes x rows x C x 4 (DESIGN.md 4.7)"}
+        kernels = hot_kernel_lines(a, ms, ms_single, ms_lazy, bn)
         cand = [k for k in ("flow_prepare", "ppm_loss") if k in kernels]
         dominant = max(cand, key=lambda k: kernels[k]["ms_per_launch"]) if cand else None
         out = {
@@ -625,6 +893,7 @@ def main():
                        "key_branch": ("second HIP stream" + (", own SyncBN process group" if a.key_bn_group and world > 1 else ""))
                                      if a.overlap_momentum else "same stream",
                        "miopen": f"immediate mode; {miopen_note}",
+                       **({"miopen_untuned_ms_per_step": untuned} if untuned is not None else {}),
                        "flow_mode": "lazy (flow + mask evaluated at the loss sample points)" if a.lazy_flow else "dense",
                        "per_gpu_batch": a.batch, "global_batch": a.batch * world,
                        "parallelism": f"dp{world}" if world > 1 else "single", "final_loss": round(final_loss, 5),
@@ -632,7 +901,11 @@ def main():
             "roofline": dict(kernel=dominant, **kernels[dominant]) if dominant else None,
             "hot_kernels": kernels,
         }
+        if extra:
+            out["extra_configs"] = extra
         if comm:
+            if ab:
+                comm["syncbn_ab"] = ab
             out["rccl"] = comm
         if world == 1 and not a.no_cpu_baseline:
             note(rank, "timing the CPU oracle on a bounded sample")

@@ -92,9 +92,13 @@ const char* pixpro_last_error(void);
  * loss_n, pos_num, pos_mean: [ndir*N]; loss: [1] = sum over directions of -2*mean_n(loss_n)
  * (PixPro.py:247,431).  Gradients (if dx != NULL) are d(grad_scale*loss)/dx, /dv.
  * Uses the single-launch MFMA kernel when P<=64 and C%128==0 (C<=256); larger grids (the 14x14
- * grid of 448^2 crops) with C in {64,128,256} and P%4==0 take the tiled 7-launch MFMA path,
+ * grid of 448^2 crops) with C in {64,128,256} and P%4==0 take the tiled 5-launch MFMA path,
  * anything else the staged generic path (both need the workspace). */
 size_t pixpro_ppm_loss_workspace_bytes(const pixpro_problem* pb);          /* 0 when the MFMA kernel applies */
+/* 1 when pixpro_ppm_loss consumes tiles of pb->layout in place for this shape (layout 1 = channels_last: the single-launch
+ * kernels and the tiled path do, the staged path does not); 0: hand it NCHW tiles.  The reference's featprop is
+ * layout-agnostic (PixPro.py:339-363); this lets the host wrapper avoid layout copies where the kernels can. */
+int pixpro_ppm_loss_layout_supported(const pixpro_problem* pb);
 size_t pixpro_ppm_loss_generic_workspace_bytes(const pixpro_problem* pb);  /* staged path, any shape */
 int pixpro_ppm_loss(const pixpro_problem* pb, const pixpro_dir* dirs, float* loss_n,
                     float* pos_num, float* pos_mean, float* loss, void* workspace,
@@ -214,6 +218,10 @@ int pixpro_corr_lookup(const float* level0, const float* level1, const float* le
  * between the calls stay with the caller (torch.distributed over RCCL):
  *   forward : pixpro_bn_stats -> all_gather(packed [2C+1]) -> pixpro_bn_apply
  *   backward: pixpro_bn_backward_reduce -> all_reduce(sums [2C]) -> pixpro_bn_backward_apply                         */
+/* Workspace of pixpro_bn_stats / pixpro_bn_backward_reduce.  Its first 4096 bytes are int32 tickets (the work-group that
+ * finishes last folds the partial sums): they must be ZERO when a call starts and are zero again when its kernel has
+ * finished, so one zero-initialised buffer serves every later call that is ordered after it (same stream).  Two calls
+ * that may run concurrently (different streams) need a workspace each.  0 = unsupported shape. */
 size_t pixpro_bn_workspace_bytes(int64_t rows, int32_t C);
 /* packed[0..C) = mean, packed[C..2C) = biased variance, packed[2C] = rows: this rank's statistics. */
 int pixpro_bn_stats(const float* x, int64_t rows, int32_t C, void* workspace, size_t workspace_bytes,

@@ -41,6 +41,7 @@ SIGNATURES = {
     "pixpro_version": (ctypes.c_int, []),
     "pixpro_last_error": (ctypes.c_char_p, []),
     "pixpro_ppm_loss_workspace_bytes": (_sz, [_PP]),
+    "pixpro_ppm_loss_layout_supported": (ctypes.c_int, [_PP]),
     "pixpro_ppm_loss_generic_workspace_bytes": (_sz, [_PP]),
     "pixpro_ppm_loss": (ctypes.c_int, [_PP, _DP, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "pixpro_ppm_loss_generic": (ctypes.c_int, [_PP, _DP, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -144,3 +145,19 @@ def ptr(t):
 
 def workspace(nbytes, device):
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+_zeroed = {}
+
+
+def zeroed_workspace(nbytes, device):
+    """A persistent workspace per (device, current stream) that was zero when it was created: for entry points whose kernels
+    need zeroed tickets on entry and leave them zeroed (pixpro_bn_stats, pixpro_bn_backward_reduce).  Calls on one stream
+    are ordered, so they share the buffer; another stream gets its own.  Grows by reallocation (the caching allocator
+    keeps the old block alive until the stream has passed the kernels that use it)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
+    buf = _zeroed.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.zeros(max(int(nbytes), 4096), dtype=torch.uint8, device=device)
+        _zeroed[key] = buf
+    return buf

@@ -43,11 +43,11 @@ def _problem(dirs, p, clamp, pos_ratio, normalize_k, grad_scale=1.0, allow_nhwc=
     N, C, H, W = d0.x.shape
     pb = nv.Problem()
     pb.N, pb.C, pb.H, pb.W = N, C, H, W
-    # channels_last activations are consumed in place by the single-launch kernel (no NCHW copies)
+    # channels_last activations are consumed in place by the single-launch kernels and by the tiled path (no NCHW copies)
     nhwc = False
     if allow_nhwc and nv.is_nhwc(d0.x):
         pb.layout, pb.ndir = 1, len(dirs)
-        nhwc = nv.load().pixpro_ppm_loss_workspace_bytes(ctypes.byref(pb)) == 0   # 0 <=> single-launch kernel applies
+        nhwc = bool(nv.load().pixpro_ppm_loss_layout_supported(ctypes.byref(pb)))
     pb.layout = int(nhwc)
     pb.p, pb.clamp, pb.pos_ratio = float(p), float(clamp), float(pos_ratio)
     pb.normalize_k, pb.ndir, pb.grad_scale = int(bool(normalize_k)), len(dirs), float(grad_scale)
@@ -152,14 +152,21 @@ class _PPMLoss(torch.autograd.Function):
         grads = ctx.grads
         if grads is None:
             return (None,) * (1 + 2 * ctx.nd)
-        # grads hold applied * d(loss)/d(x,v); bring them to the upstream scalar on the device (the kernel
-        # returns at once when the ratio is 1, the usual case) - no host sync, safe under retain_graph
+        # The kernel wrote d(loss)/d(x,v) for an upstream of 1.  First call: bring the buffer to the upstream scalar in place,
+        # on the device (the kernel returns at once when it is 1, the usual case) - no host sync - and hand out views of it.
+        # The views stay referenced from ctx: AccumulateGrad keeps ("steals") a gradient tensor nobody else holds, and a
+        # leaf's .grad that aliased this buffer would be accumulated into IN PLACE by a second backward (retain_graph) -
+        # corrupting what that call rescales.  With the reference held, a leaf gets its own copy; the usual consumer (the
+        # projector's conv backward) only reads.  Later calls never write the buffer: their result is a fresh tensor.
         g = gloss.detach().to(torch.float32).reshape(1)
         applied = getattr(ctx, "applied", None)
-        ratio = (g if applied is None else g / applied).contiguous()
-        nv.call("pixpro_scale_by_device_scalar", nv.ptr(grads), grads.numel(), nv.ptr(ratio), nv.stream())  # dense buffer
-        ctx.applied = g.clone()
-        return (None,) + tuple(grads[i] for i in range(2 * ctx.nd))
+        if applied is None:
+            nv.call("pixpro_scale_by_device_scalar", nv.ptr(grads), grads.numel(), nv.ptr(g.contiguous()), nv.stream())  # dense buffer
+            ctx.applied = g.clone()
+            ctx.handed = tuple(grads[i] for i in range(2 * ctx.nd))
+            return (None,) + ctx.handed
+        out = grads * (g / applied)          # same strides (dense), channels_last slices stay channels_last
+        return (None,) + tuple(out[i] for i in range(2 * ctx.nd))
 
 
 def ppm_loss(dirs, p, clamp, pos_ratio, normalize_k=True, want_pred=False, generic=False):

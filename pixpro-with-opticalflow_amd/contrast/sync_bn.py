@@ -95,8 +95,10 @@ class _FusedBN(torch.autograd.Function):
         wsb = nv.load().pixpro_bn_workspace_bytes(rows, C)
         if wsb == 0:
             raise RuntimeError(f"FusedSyncBatchNorm: unsupported shape rows={rows}, C={C} (C must be a multiple of 4)")
-        ws = nv.workspace(wsb, dev)
-        packed = torch.empty(G, 2 * C + 1, **f32)
+        ws = nv.zeroed_workspace(wsb, dev)            # tickets + partial sums: one buffer per stream, reused by every layer
+        # one allocation for the four small per-layer records (16-B aligned pieces: C % 4 == 0)
+        small = torch.empty(G * (2 * C + 4) + G * 4 * C, **f32)
+        packed = small[:G * (2 * C + 1)].view(G, 2 * C + 1)
         for g in range(G):
             nv.call("pixpro_bn_stats", nv.ptr(_part(x, g, G)), rows, C, nv.ptr(ws), wsb, nv.ptr(packed[g]), nv.stream())
         world = _world(group)
@@ -113,7 +115,8 @@ class _FusedBN(torch.autograd.Function):
         else:
             gathered = packed.reshape(G, 1, 2 * C + 1)
         y = torch.empty_like(x)
-        mean, invstd, scale_shift = torch.empty(G, C, **f32), torch.empty(G, C, **f32), torch.empty(G, 2 * C, **f32)
+        rest = small[G * (2 * C + 4):]
+        mean, invstd, scale_shift = rest[:G * C].view(G, C), rest[G * C:2 * G * C].view(G, C), rest[2 * G * C:].view(G, 2 * C)
         for g in range(G):         # view after view: the running statistics see the same sequence of updates as G passes
             nv.call("pixpro_bn_apply", nv.ptr(gathered[g]), world, nv.ptr(_part(x, g, G)), nv.ptr(_part(residual, g, G)),
                     nv.ptr(weight), nv.ptr(bias), nv.ptr(running_mean), nv.ptr(running_var), float(momentum), float(eps),
@@ -134,12 +137,13 @@ class _FusedBN(torch.autograd.Function):
         dev = x.device
         f32 = dict(dtype=torch.float32, device=dev)
         wsb = nv.load().pixpro_bn_workspace_bytes(rows, C)
-        ws = nv.workspace(wsb, dev)
-        sums = torch.empty(G, 2 * C, **f32)
+        ws = nv.zeroed_workspace(wsb, dev)
         need_w = weight is not None and ctx.needs_input_grad[1]
         need_b = ctx.needs_input_grad[2]
-        gw = torch.empty(G, C, **f32) if need_w else None
-        gb = torch.empty(G, C, **f32) if need_b else None
+        small = torch.empty(G * 4 * C, **f32)         # sums [G,2C] | grad_weight [G,C] | grad_bias [G,C]
+        sums = small[:2 * G * C].view(G, 2 * C)
+        gw = small[2 * G * C:3 * G * C].view(G, C) if need_w else None
+        gb = small[3 * G * C:].view(G, C) if need_b else None
         for g in range(G):
             nv.call("pixpro_bn_backward_reduce", nv.ptr(_part(dy, g, G)), nv.ptr(_part(x, g, G)), nv.ptr(_part(y, g, G)),
                     nv.ptr(scale_shift[g] if scale_shift is not None else None), nv.ptr(mean[g]), nv.ptr(invstd[g]),
@@ -172,8 +176,22 @@ def _flush_counter_hook(module, prefix, keep_vars):
     module._flush_counter()
 
 
+def flush_counters(module):
+    """Apply every pending `num_batches_tracked` increment below `module`.  Call it before anything that reads buffers
+    WITHOUT going through attribute access or state_dict() - `module.buffers()` / `named_buffers()` / `_buffers` walks,
+    DistributedDataParallel(broadcast_buffers=True), buffer-copying EMA code: those see the tensor as it is."""
+    for m in module.modules():
+        if isinstance(m, FusedSyncBatchNorm):
+            m._flush_counter()
+    return module
+
+
 class FusedSyncBatchNorm(nn.modules.batchnorm._BatchNorm):
-    """Drop-in for nn.BatchNorm2d / nn.SyncBatchNorm with optional fused tail: `bn(x, residual=None, relu=False)`."""
+    """Drop-in for nn.BatchNorm2d / nn.SyncBatchNorm with optional fused tail: `bn(x, residual=None, relu=False)`.
+
+    Limitation: `num_batches_tracked` is incremented lazily (on attribute access, state_dict(), load); a reader that walks
+    `buffers()` / `named_buffers()` directly sees a stale counter unless it calls `sync_bn.flush_counters(model)` first
+    (running_mean / running_var are always current)."""
 
     fused = True
 

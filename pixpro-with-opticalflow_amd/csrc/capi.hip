@@ -30,6 +30,9 @@ int check_launch(const char* what) {
 bool fused_supported(const pixpro_problem& pb);
 int run_fused(const pixpro_problem& pb, const pixpro_dir* dirs, float* loss_n, float* pos_num, float* pos_mean,
               hipStream_t st);
+bool fused_nhwc_supported(const pixpro_problem& pb);
+int run_fused_nhwc(const pixpro_problem& pb, const pixpro_dir* dirs, float* loss_n, float* pos_num, float* pos_mean,
+                   hipStream_t st);
 size_t generic_workspace_bytes(const pixpro_problem& pb);
 bool tiled_supported(const pixpro_problem& pb);
 size_t tiled_workspace_bytes(const pixpro_problem& pb);
@@ -119,6 +122,12 @@ size_t pixpro_ppm_loss_workspace_bytes(const pixpro_problem* pb) {
   return g > t ? g : t;
 }
 
+int pixpro_ppm_loss_layout_supported(const pixpro_problem* pb) {
+  if (!pb) return 0;
+  if (pb->layout == 0) return 1;
+  return pb->layout == 1 && (fused_supported(*pb) || (tiled_supported(*pb) && !getenv("PIXPRO_NO_TILED"))) ? 1 : 0;
+}
+
 size_t pixpro_ppm_loss_generic_workspace_bytes(const pixpro_problem* pb) {
   if (!pb) return 0;
   return generic_workspace_bytes(*pb);
@@ -143,10 +152,14 @@ int pixpro_ppm_loss(const pixpro_problem* pb, const pixpro_dir* dirs, float* los
                            (uintptr_t)q.pred;      // 16 B per lane loads / stores / LDS-DMA in the MFMA paths
     if (bits & 15) aligned = false;
   }
-  if (pb->layout == 1 && !(fused_supported(*pb) && aligned))
-    return bad("NHWC tiles are handled by the single-launch kernel only (P <= 49, C in {128, 256}, 16-B aligned)");
+  if (pb->layout == 1 && !((fused_supported(*pb) || tiled_supported(*pb)) && aligned))
+    return bad("NHWC tiles are handled by the single-launch kernel (P <= 49, C in {128, 256}) and the tiled path "
+               "(C in {64, 128, 256}, P % 4 == 0) only, 16-B aligned: see pixpro_ppm_loss_layout_supported");
   if (fused_supported(*pb) && aligned) {
-    if (int e = run_fused(*pb, dirs, loss_n, pos_num, pos_mean, (hipStream_t)stream)) return e;
+    // channels_last tiles of the 7 x 7 grid at C = 256 (what the pre-training step runs): the NHWC-native persistent kernel
+    if (int e = fused_nhwc_supported(*pb) ? run_fused_nhwc(*pb, dirs, loss_n, pos_num, pos_mean, (hipStream_t)stream)
+                                          : run_fused(*pb, dirs, loss_n, pos_num, pos_mean, (hipStream_t)stream))
+      return e;
     return run_finalize(loss_n, loss, pb->N * pb->ndir, pb->N, (hipStream_t)stream);
   }
   if (!workspace) return bad("this shape takes a multi-launch path and needs a workspace");

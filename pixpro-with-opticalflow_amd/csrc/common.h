@@ -503,6 +503,34 @@ __device__ __forceinline__ void frame_size_uniform(const pixpro_problem& pb, con
   else { sc_float_ptr s = (sc_float_ptr)(uintptr_t)d.coord_q; Ho = (int)s[9]; Wo = (int)s[8]; }
 }
 
+// ---- asynchronous global -> LDS copies (global_load_lds_dwordx4) ------------------------------------------------------
+// One wave instruction moves 64 x 16 B: every lane names its own SOURCE address, the destination is the wave-uniform LDS
+// base + 16 * lane.  A slab image is therefore linear in LDS and any swizzle is applied to the source side and to the
+// reads (the same involution on both).  The copies are counted in vmcnt; nothing orders them against LDS reads except the
+// issuing wave's s_waitcnt vmcnt(n) followed by a barrier, so the loops below use raw s_barrier (a __syncthreads() would
+// drain every copy in flight with vmcnt(0)).
+// The copy is issued from inline assembly on purpose: hipcc tracks an LDS-DMA it knows about as a pending LDS write and,
+// where it cannot prove that a later ds_read touches another buffer of the ring, puts s_waitcnt vmcnt(0) in front of the
+// read - which drains the slabs that were requested AHEAD as well (found in the strip kernels' ISA in round 3: every slab
+// waited for the copies issued in the same iteration).  The waits are placed by hand below, by count.  M0 (the LDS base of
+// the copy) is saved and restored inside the statement.
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+__device__ __forceinline__ void dma16(const float* src, float* lds_wave_base) {
+  const unsigned lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr_t)lds_wave_base);
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(src), "s"(lds)
+               : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void lds_barrier() {          // LDS traffic of this wave retired, then the work-group barrier
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
 // A = clamp(S,min=c) (+1e-6 if p<1) ** p  and  D = dA/dS  (PixPro.py:355-358).
 __device__ __forceinline__ void pow_map(float S, float p, float clampv, float& A, float& D) {
   float B = fmaxf(S, clampv);

@@ -19,6 +19,8 @@
 // fragments; the 16-column tiles are dealt evenly to the strips; every epilogue moves its global traffic in 256-B rows
 // through LDS; the work-groups of one (direction, sample) are placed on one XCD.  Same math and tolerances as the other
 // two paths; the bit-exact part (points, threshold, mask) uses the same helpers as ppm_fused.hip.
+#include <type_traits>
+
 #include "common.h"
 
 namespace pixpro {
@@ -39,6 +41,7 @@ struct TlWs {                    // workspace carve (floats unless noted)
   float *dY;                     // [B][C][P]
   unsigned long long* bits;      // [B][P][W64]
   float* zero;                   // 16 floats of zeros (written by k_tl_pre): what the copies fetch for k beyond P
+  float *xT, *vT, *kT;           // channels_last inputs (layout 1): [B][C][P] images written by k_tl_pre, else null
 };
 
 inline size_t al256(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
@@ -47,7 +50,7 @@ size_t tl_bytes(const pixpro_problem& pb) {
   const size_t B = (size_t)pb.N * pb.ndir, P = (size_t)pb.H * pb.W, R = (size_t)pb.C * P, Q = P * P, W64 = (P + 63) / 64;
   const size_t strips = (P + 63) / 64;
   return 3 * al256(B * P * 4) + al256(B * 4 * 4) + al256(B * strips * 4) + 4 * al256(B * Q * 4) + al256(B * R * 4) +
-         al256(B * P * W64 * 8) + 256 + 4096;
+         al256(B * P * W64 * 8) + 256 + 4096 + (pb.layout == 1 ? 3 * al256(B * R * 4) : 0);
 }
 
 TlWs tl_carve(void* ws, const pixpro_problem& pb) {
@@ -63,6 +66,10 @@ TlWs tl_carve(void* ws, const pixpro_problem& pb) {
   w.dY = (float*)take(B * R * 4);
   w.bits = (unsigned long long*)take(B * P * W64 * 8);
   w.zero = (float*)take(64);
+  w.xT = w.vT = w.kT = nullptr;
+  if (pb.layout == 1) {
+    w.xT = (float*)take(B * R * 4); w.vT = (float*)take(B * R * 4); w.kT = (float*)take(B * R * 4);
+  }
   return w;
 }
 
@@ -103,8 +110,9 @@ __device__ __forceinline__ float cnt_of(const float* __restrict__ cnt, int b) {
 //   work-groups [6 B, 6 B + PREP_S B):  sample points (flow-displaced bin centres), positive-pair BIT rows, counts; every
 //                                work-group of a pair takes every PREP_S-th group of 4 rows
 __global__ void __launch_bounds__(TB) k_tl_pre(pixpro_problem pb, Dirs D, TlWs w) {
-  __shared__ float qx[TL_MAXP], qy[TL_MAXP], kx[TL_MAXP], ky[TL_MAXP];
-  __shared__ int valid[TL_MAXP];
+  __shared__ __attribute__((aligned(16))) float pts[5 * TL_MAXP];
+  float *qx = pts, *qy = pts + TL_MAXP, *kx = pts + 2 * TL_MAXP, *ky = pts + 3 * TL_MAXP;
+  int* valid = reinterpret_cast<int*>(pts + 4 * TL_MAXP);
   __shared__ float sT;
   __shared__ int wcnt[TB / 64];
   const int B = pb.N * pb.ndir, P = pb.H * pb.W, W64 = (P + 63) / 64, C = pb.C;
@@ -118,6 +126,45 @@ __global__ void __launch_bounds__(TB) k_tl_pre(pixpro_problem pb, Dirs D, TlWs w
     float* o = (which == 0 ? w.rx : which == 1 ? w.rv : w.rk) + (size_t)b * P;
     const int f4 = P / 4, h0 = (f4 + 1) / 2, c0 = half ? h0 : 0, fw = half ? f4 - h0 : h0;   // this half's float4 columns
     if (fw == 0) return;
+    if (pb.layout == 1) {
+      // channels_last input: the sample is [P][C].  This work-group owns the pixels [4 c0, 4 (c0 + fw)) with ALL channels:
+      // the norms are sums over one contiguous 1-KB row per pixel, and since every element passes through here anyway the
+      // [C][P] image the products read is written on the way (transposed through LDS, 64 channels x up to 64 pixels at a
+      // time; rows of the image leave as 16 B per lane) - no layout copies on the host side.
+      float* img = (which == 0 ? w.xT : which == 1 ? w.vT : w.kT) + (size_t)b * C * P;
+      constexpr int PXB = 64, TRS = PXB + 1;                  // pixels per block; odd row stride: conflict-free both ways
+      float* tr = pts;                                        // the point arrays are not in use in these work-groups
+      static_assert(64 * TRS + PXB <= 5 * TL_MAXP, "transposition tile fits in the point arrays");
+      float* nrm = tr + 64 * TRS;                             // [PXB] sums of squares
+      const int p0 = 4 * c0, npx = 4 * fw, pr = t >> 4, l4 = t & 15;
+      const bool unit = which == 2 && !pb.normalize_k;
+      for (int pb0 = 0; pb0 < npx; pb0 += PXB) {
+        const int nb = min(PXB, npx - pb0);
+        for (int j = t; j < nb; j += TB) nrm[j] = 0.f;
+        for (int cc = 0; cc < C; cc += 64) {
+          __syncthreads();                                    // tr free again (and nrm zeroed)
+          for (int pp = pr; pp < nb; pp += TB / 16) {
+            const float4 v = *reinterpret_cast<const float4*>(s + (size_t)(p0 + pb0 + pp) * C + cc + 4 * l4);
+            tr[(4 * l4 + 0) * TRS + pp] = v.x; tr[(4 * l4 + 1) * TRS + pp] = v.y;
+            tr[(4 * l4 + 2) * TRS + pp] = v.z; tr[(4 * l4 + 3) * TRS + pp] = v.w;
+            float q = __builtin_fmaf(v.x, v.x, __builtin_fmaf(v.y, v.y, __builtin_fmaf(v.z, v.z, v.w * v.w)));
+            q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64); q += __shfl_xor(q, 8, 64);
+            if (l4 == 0) nrm[pp] += q;                         // the same thread owns pixel pp in every channel block
+          }
+          __syncthreads();
+          const int n4 = nb / 4;                               // P % 4 == 0: whole float4s
+          for (int e = t; e < 64 * n4; e += TB) {
+            const int c = e / n4, j4 = e - c * n4;
+            const float* r = tr + c * TRS + 4 * j4;
+            *reinterpret_cast<float4*>(img + (size_t)(cc + c) * P + p0 + pb0 + 4 * j4) = make_float4(r[0], r[1], r[2], r[3]);
+          }
+        }
+        __syncthreads();
+        for (int j = t; j < nb; j += TB) o[p0 + pb0 + j] = unit ? 1.f : 1.f / fmaxf(sqrtf(nrm[j]), 1e-12f);
+        __syncthreads();
+      }
+      return;
+    }
     if (which == 2 && !pb.normalize_k) {
       for (int j = t; j < 4 * fw; j += TB) o[4 * c0 + j] = 1.f;
       return;
@@ -232,33 +279,7 @@ __device__ __forceinline__ void xcd_item(int per, int B, int& b, int& item) {
   }
 }
 
-// ---- asynchronous global -> LDS copies (global_load_lds_dwordx4) ------------------------------------------------------
-// One wave instruction moves 64 x 16 B: every lane names its own SOURCE address, the destination is the wave-uniform LDS
-// base + 16 * lane.  A slab image is therefore linear in LDS and any swizzle is applied to the source side and to the
-// reads (the same involution on both).  The copies are counted in vmcnt; nothing orders them against LDS reads except the
-// issuing wave's s_waitcnt vmcnt(n) followed by a barrier, so the loops below use raw s_barrier (a __syncthreads() would
-// drain every copy in flight with vmcnt(0)).
-// The copy is issued from inline assembly on purpose: hipcc tracks an LDS-DMA it knows about as a pending LDS write and,
-// where it cannot prove that a later ds_read touches another buffer of the ring, puts s_waitcnt vmcnt(0) in front of the
-// read - which drains the slabs that were requested AHEAD as well (found in the strip kernels' ISA in round 3: every slab
-// waited for the copies issued in the same iteration).  The waits are placed by hand below, by count.  M0 (the LDS base of
-// the copy) is saved and restored inside the statement.
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-__device__ __forceinline__ void dma16(const float* src, float* lds_wave_base) {
-  const unsigned lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr_t)lds_wave_base);
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(src), "s"(lds)
-               : "memory");
-}
-template <int N>
-__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-__device__ __forceinline__ void lds_barrier() {          // LDS traffic of this wave retired, then the work-group barrier
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-}
+// (dma16, wait_vm, lds_barrier: asynchronous global -> LDS copies, common.h)
 
 // ---- P x P products over K = C on 64 x 64 tiles --------------------------------------------------------------------------
 // NP 64 x 64 x C products at once: acc[q][i][j] += sum_c L_q[c*P + m0_q + ..] * R_q[c*P + n0_q + ..]; wave w owns the
@@ -317,8 +338,11 @@ __device__ __forceinline__ void gram_core(f32x4 (&acc)[NP][GNI][GNJ], const Gram
 #pragma unroll
   for (int e = 0; e < PIECES; ++e) {
     const int f = PIECES * wave + e, o = f / OPP, kk = 4 * (f % OPP) + lq, ch = lr ^ ((kk & 1) << 2);
-    const GramOp& g_ = op[NP == 1 ? 0 : (o >> 1)];
-    src[e] = ((o & 1) ? g_.Rm : g_.L) + (size_t)kk * P + min(((o & 1) ? g_.n0 : g_.m0) + 4 * ch, P - 4);
+    // Every product of a launch reads the same two tensors (only the tile origins differ), and the origin is picked by
+    // arithmetic: indexing `op` with the run-time product number - or selecting its fields - put the array into scratch.
+    const int q1 = NP > 1 ? (o >> 1) : 0;
+    const int m0s = op[0].m0 + q1 * (op[NP - 1].m0 - op[0].m0), n0s = op[0].n0 + q1 * (op[NP - 1].n0 - op[0].n0);
+    src[e] = ((o & 1) ? op[0].Rm : op[0].L) + (size_t)kk * P + min(((o & 1) ? n0s : m0s) + 4 * ch, P - 4);
   }
   const size_t slab_step = (size_t)GKT * P;
   auto issue = [&](int s) {
@@ -446,7 +470,7 @@ __global__ void __launch_bounds__(TBG) k_tl_gram(Dirs D, TlWs w, int N, int C, i
     // S is symmetric: only the tiles (ti <= tj) are computed (10 of 16 at P = 196) and written twice.  Round 3: both
     // images leave through LDS - the accumulator layout (16 columns x 4 rows per lane group) stored 64-B pieces of four
     // rows per instruction, the mirror image 16-B pieces of 64 rows; now every store instruction writes four 256-B rows.
-    const float* x = dd.x + (size_t)(b % N) * R;
+    const float* x = w.xT ? w.xT + (size_t)b * R : dd.x + (size_t)(b % N) * R;     // channels_last: k_tl_pre's [C][P] image
     f32x4 acc[1][GNI][GNJ];
 #pragma unroll
     for (int i = 0; i < GNI; ++i)
@@ -501,7 +525,7 @@ __global__ void __launch_bounds__(TBG) k_tl_gram(Dirs D, TlWs w, int N, int C, i
     // ONE pass over C (round 2 ran them one after the other: two pipeline fills, a third of the occupancy for the partner
     // tile kept in LDS meanwhile); the diagonal tiles need one product only.
     const float* dY = w.dY + (size_t)b * R;
-    const float* v = dd.v + (size_t)(b % N) * R;
+    const float* v = w.vT ? w.vT + (size_t)b * R : dd.v + (size_t)(b % N) * R;
     const float* rv = w.rv + (size_t)b * P;
     const float* Dm = w.Dm + (size_t)b * Q;
     f32x4 acc[2][GNI][GNJ];
@@ -530,9 +554,10 @@ __global__ void __launch_bounds__(TBG) k_tl_gram(Dirs D, TlWs w, int N, int C, i
     // dSs[i][j] = dS[i][j] + dS[j][i] with dS = rv[col] dA o D and D symmetric:  dSs[i][j] = D[i][j] (U1[i][j] + U2[j][i]),
     // U = rv[col] * dA staged in LDS per tile.  D is read row-major where the result is written (256-B rows); round 2
     // multiplied by D in the accumulator layout: 32 loads of 64-B pieces of four rows per lane.
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      if (half && ti == tj) break;
+    // (two straight-line calls: a loop with `break` over `half` kept acc[half] dynamically indexed - 64 B of scratch per
+    // thread in the only kernel of this file that had any)
+    auto stage_u = [&](auto hc) {
+      constexpr int half = decltype(hc)::value;
       const int n0 = half ? i0 : j0;
       float* Lt = half ? T1 : T0;
 #pragma unroll
@@ -544,7 +569,9 @@ __global__ void __launch_bounds__(TBG) k_tl_gram(Dirs D, TlWs w, int N, int C, i
 #pragma unroll
           for (int r = 0; r < 4; ++r) Lt[(wm + 16 * i + 4 * lq + r) * EPS + ln] = acc[half][i][j][r] * rvn;
         }
-    }
+    };
+    stage_u(std::integral_constant<int, 0>{});
+    if (ti != tj) stage_u(std::integral_constant<int, 1>{});
     lds_barrier();
     const float* T2 = ti == tj ? T0 : T1;
     float* out = w.dSs + (size_t)b * Q;
@@ -720,6 +747,13 @@ __global__ void __launch_bounds__(64 * NWS) k_tl_strip(pixpro_problem pb, Dirs D
   constexpr int MC = (MW >= 2 && NWS == 4) ? 2 : 1;           // 16-row tiles per staging pass
   static_assert(SNB * StripRing<MW, NWS>::SLAB >= NWS * 16 * MC * EPS, "staging tiles fit in the ring");
   float* scr = ring + wave * (16 * MC * EPS);
+  // Lanes of ONE wave exchange values through `scr` (lane A writes, lane B reads another index).  The hardware runs a
+  // wave's LDS operations in order; this keeps the compiler from reordering the two per-thread accesses it sees.
+  auto wave_sync = [] {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
   auto rows_out = [&](float* __restrict__ dst, auto value) {      // value(m, nn, r) in accumulator layout -> rows of dst
 #pragma unroll
     for (int pp = 0; pp < MW / MC; ++pp) {
@@ -729,6 +763,7 @@ __global__ void __launch_bounds__(64 * NWS) k_tl_strip(pixpro_problem pb, Dirs D
         for (int nn = 0; nn < 4; ++nn)
 #pragma unroll
           for (int r = 0; r < 4; ++r) scr[(16 * mm + 4 * lq + r) * EPS + 16 * nn + lr] = value(MC * pp + mm, nn, r);
+      wave_sync();
 #pragma unroll
       for (int i = 0; i < 4 * MC; ++i) {
         const int row = 4 * i + (lane >> 4), c4 = lane & 15;
@@ -736,6 +771,7 @@ __global__ void __launch_bounds__(64 * NWS) k_tl_strip(pixpro_problem pb, Dirs D
           *reinterpret_cast<float4*>(dst + (size_t)(wave * 16 * MW + 16 * MC * pp + row) * P + n0 + 4 * c4) =
               *reinterpret_cast<const float4*>(scr + row * EPS + 4 * c4);
       }
+      wave_sync();
     }
   };
   auto rows_in = [&](const float* __restrict__ src, auto sink) {   // rows of src -> sink(m, nn, r, value)
@@ -749,12 +785,41 @@ __global__ void __launch_bounds__(64 * NWS) k_tl_strip(pixpro_problem pb, Dirs D
           v = *reinterpret_cast<const float4*>(src + (size_t)(wave * 16 * MW + 16 * MC * pp + row) * P + n0 + 4 * c4);
         *reinterpret_cast<float4*>(scr + row * EPS + 4 * c4) = v;
       }
+      wave_sync();
 #pragma unroll
       for (int mm = 0; mm < MC; ++mm)
 #pragma unroll
         for (int nn = 0; nn < 4; ++nn)
 #pragma unroll
           for (int r = 0; r < 4; ++r) sink(MC * pp + mm, nn, r, scr[(16 * mm + 4 * lq + r) * EPS + 16 * nn + lr]);
+      wave_sync();
+    }
+  };
+  // channels_last outputs (pred, dv, dx are [P][C]): the wave's 16 MW channels of a pixel are contiguous there (64 / 128 B), so
+  // the staging tile is transposed - [32 pixels][16 MW channels + 4] - filled with one 16-B write per accumulator tile and lane
+  // (its four registers are four consecutive channels of one pixel) and emptied pixel row by pixel row, 16 B per lane.
+  const bool nhwc = pb.layout == 1;
+  constexpr int CW = 16 * MW, PXS = CW + 4, LPP = CW / 4;          // channels per wave; staging row stride; lanes per pixel
+  static_assert(SNB * StripRing<MW, NWS>::SLAB >= NWS * 32 * PXS, "transposed staging tiles fit in the ring");
+  float* scrT = ring + wave * (32 * PXS);
+  auto pix_out = [&](float* __restrict__ dst, auto value) {        // value(m, nn, r) in accumulator layout -> pixel rows of dst
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int m = 0; m < MW; ++m)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+          *reinterpret_cast<float4*>(scrT + (16 * q + lr) * PXS + 16 * m + 4 * lq) =
+              make_float4(value(m, 2 * h + q, 0), value(m, 2 * h + q, 1), value(m, 2 * h + q, 2), value(m, 2 * h + q, 3));
+      wave_sync();
+#pragma unroll
+      for (int i = 0; i < 32 * LPP / 64; ++i) {
+        const int px = (64 / LPP) * i + lane / LPP, l4 = lane % LPP, col = n0 + 32 * h + px;
+        if (col < pend)
+          *reinterpret_cast<float4*>(dst + (size_t)col * C + wave * CW + 4 * l4) =
+              *reinterpret_cast<const float4*>(scrT + px * PXS + 4 * l4);
+      }
+      wave_sync();
     }
   };
   const f32x4 z = {0.f, 0.f, 0.f, 0.f};
@@ -765,8 +830,8 @@ __global__ void __launch_bounds__(64 * NWS) k_tl_strip(pixpro_problem pb, Dirs D
     for (int nn = 0; nn < 4; ++nn) acc[m][nn] = z;
 
   if (MODE == 0) {
-    const float* v = dd.v + so;
-    const float* kk = dd.k + so;
+    const float* v = nhwc ? w.vT + (size_t)b * R : dd.v + so;
+    const float* kk = nhwc ? w.kT + (size_t)b * R : dd.k + so;
     const float* rk = w.rk + (size_t)b * P;
     const float* Av = w.Av + (size_t)b * Q;
     // ---- Y = v^ A = v (diag(rv) A): the scale sits in the COLUMNS of the stored matrix AvT[n][k] = rv[k] A[n][k] (A is
@@ -802,7 +867,8 @@ __global__ void __launch_bounds__(64 * NWS) k_tl_strip(pixpro_problem pb, Dirs D
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[m][nn][r] = acc[m][nn][r] * ry[nn];
     if (dd.pred) {
-      rows_out(dd.pred + so, [&](int m, int nn, int r) { return acc[m][nn][r]; });
+      auto val = [&](int m, int nn, int r) { return acc[m][nn][r]; };
+      if (nhwc) pix_out(dd.pred + so, val); else rows_out(dd.pred + so, val);
       lds_barrier();             // the staging tiles lie where the next product's first slabs land
     }
     // ---- G = k^ M^T, M expanded from the bit rows: B(k = j, n = i) = bit j of row i
@@ -852,7 +918,8 @@ __global__ void __launch_bounds__(64 * NWS) k_tl_strip(pixpro_problem pb, Dirs D
     // item < ns: dV^ = dY A, dv = (dV^ - v^ s) / n_v ;  item >= ns: dX^ = x^ dSs', dx = (dX^ - x^ s) / n_x
     // (both products in one work-group - a loop over the two - compiles to 256 VGPRs and runs slower: 204 us vs 127 us)
     const bool isx = item >= ns;
-    const float* src = (isx ? dd.x : dd.v) + so;               // the tensor being differentiated
+    // the tensor being differentiated ([C][P]: the caller's, or k_tl_pre's image of a channels_last one)
+    const float* src = nhwc ? (isx ? w.xT : w.vT) + (size_t)b * R : (isx ? dd.x : dd.v) + so;
     const float* rn = (isx ? w.rx : w.rv) + (size_t)b * P;
     const float* Mat = (isx ? w.dSs : w.A) + (size_t)b * Q;
     const float* Aop = isx ? src : w.dY + (size_t)b * R;
@@ -868,9 +935,10 @@ __global__ void __launch_bounds__(64 * NWS) k_tl_strip(pixpro_problem pb, Dirs D
         s[nn] = __builtin_fmaf(hat[m][nn][r], acc[m][nn][r], s[nn]);
       });
     strip_colsum<NWS>(s, part);
-    if (!(TL_ABL & 1) || s[0] == 123.456f)
-      rows_out((isx ? dd.dx : dd.dv) + so,
-               [&](int m, int nn, int r) { return (acc[m][nn][r] - hat[m][nn][r] * s[nn]) * rj[nn]; });
+    if (!(TL_ABL & 1) || s[0] == 123.456f) {
+      auto val = [&](int m, int nn, int r) { return (acc[m][nn][r] - hat[m][nn][r] * s[nn]) * rj[nn]; };
+      if (nhwc) pix_out((isx ? dd.dx : dd.dv) + so, val); else rows_out((isx ? dd.dx : dd.dv) + so, val);
+    }
   }
 }
 
@@ -917,7 +985,7 @@ int run_tiled_c(const pixpro_problem& pb, const Dirs& D, const TlWs& w, float* l
 
 bool tiled_supported(const pixpro_problem& pb) {
   const int P = pb.H * pb.W;
-  return pb.layout == 0 && (pb.C == 64 || pb.C == 128 || pb.C == 256) && P % 4 == 0 && P >= 4 && P <= TL_MAXP;
+  return (pb.layout == 0 || pb.layout == 1) && (pb.C == 64 || pb.C == 128 || pb.C == 256) && P % 4 == 0 && P >= 4 && P <= TL_MAXP;
 }
 
 size_t tiled_workspace_bytes(const pixpro_problem& pb) { return tl_bytes(pb); }

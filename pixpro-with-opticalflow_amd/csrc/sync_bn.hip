@@ -7,13 +7,18 @@
 // (profiles/r01_syncbn_microbench.txt).  These kernels keep the same split (local statistics | exchange | apply),
 // so the collectives stay where torch has them, and stream x as [M = N*H*W rows][C] with 16 B per lane:
 //
-//   forward   k_stats (1 read of x)  -> k_stats_finalize -> [all_gather of 2C+1 floats] -> k_apply (merges in its prologue)
+//   forward   k_stats (1 read of x; its last work-group per channel chunk folds the partials)
+//             -> [all_gather of 2C+1 floats] -> k_apply (merges the ranks' records in its prologue)
 //             k_apply: y = relu?( (x-mean)*invstd*w + b (+ residual) )                      (read x [,res], write y)
-//   backward  k_bwd_reduce: dz = dy * (y > 0)?; sum dz, sum dz*(x-mean)                      (read dy, x [,y])
-//             -> k_bwd_finalize -> [all_reduce of 2C floats] -> k_bwd_apply: dx [, dres = dz] (read dy, x [,y])
+//   backward  k_bwd_reduce: dz = dy * (y > 0)?; sum dz, sum dz*(x-mean)                      (read dy, x [,y]; same fold)
+//             -> [all_reduce of 2C floats] -> k_bwd_apply: dx [, dres = dz]                   (read dy, x [,y])
 //
 // Statistics are accumulated as shifted sums (pivot = the channel's first element), so the variance does not suffer
-// the E[x^2]-E[x]^2 cancellation; partial sums are combined in a fixed order (deterministic, no atomics).
+// the E[x^2]-E[x]^2 cancellation; partial sums are combined in a fixed order (deterministic; the only atomic is the ticket
+// that tells a work-group it is the last of its channel chunk to finish - which one that is does not enter the result).
+// Round 4: the partials used to be folded by two one-block launches per layer and direction (k_stats_finalize,
+// k_bwd_finalize: 324 launches, 5.7 ms per ResNet-50 step, serial between the streaming kernels); now the work-group that
+// draws the last ticket of its chunk does it before it exits.
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -90,9 +95,11 @@ __device__ __forceinline__ void block_rows_sum(float4& a, float4& b, int TX, int
   }
 }
 
-// partial[by][0][C] = sum (x - K), partial[by][1][C] = sum (x - K)^2,  K = x[0][c]
+// partial[by][0][C] = sum (x - K), partial[by][1][C] = sum (x - K)^2,  K = x[0][c]; the last work-group of a chunk:
+// packed[0..C) = mean, packed[C..2C) = biased variance, packed[2C] = M     (what one rank contributes)
 __global__ void __launch_bounds__(BN_TPB)
-k_stats(const float* __restrict__ x, float* __restrict__ partial, int64_t M, int C4, int TX, int TY) {
+k_stats(const float* __restrict__ x, int* __restrict__ tickets, float* __restrict__ partial, float* __restrict__ packed,
+        int64_t M, int C4, int TX, int TY) {
   __shared__ float4 sh[2 * BN_TPB];
   float4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
   const float4 K = ld4(x, blockIdx.x * TX + (threadIdx.x & (TX - 1)));
@@ -112,40 +119,46 @@ k_stats(const float* __restrict__ x, float* __restrict__ partial, int64_t M, int
   }
 }
 
-// Column sums of the [nblk][2][C] partials: 8 channels x 32 row groups per block, double accumulation (the partials are
-// long sums themselves), fixed order.  Returns the two totals of channel c in the g == 0 lanes.
-constexpr int FIN_CH = 8, FIN_G = BN_TPB / FIN_CH;
-__device__ __forceinline__ bool finalize_sums(const float* __restrict__ partial, int nblk, int C, int& c, double& s,
-                                              double& q) {
-  __shared__ double red[2][FIN_G][FIN_CH];
-  const int lc = threadIdx.x % FIN_CH, g = threadIdx.x / FIN_CH;
-  c = blockIdx.x * FIN_CH + lc;
-  s = 0.0; q = 0.0;
-  if (c < C)
-    for (int b = g; b < nblk; b += FIN_G) {
-      s += (double)partial[(int64_t)b * 2 * C + c];
-      q += (double)partial[(int64_t)b * 2 * C + C + c];
+// ---- last-work-group fold -------------------------------------------------------------------------------------------
+// The workspace starts with BN_HDR int32 tickets (one per channel chunk = blockIdx.x), zero before the launch; every
+// work-group publishes its partial rows (release), draws a ticket, and the one that draws gridDim.y - 1 sums the gridDim.y
+// partial rows of its chunk in double (the partials are long sums themselves), in a fixed order, and puts the ticket back
+// to zero for the next launch on the stream.  Returns true in the threads (ty == 0) that hold the totals of float4 column
+// c4: s = first partial plane, q = second.
+constexpr int BN_HDR = 1024;           // tickets: channel chunks per launch (C / 4 / TX <= 1024)
+struct D4 { double x, y, z, w; };
+__device__ __forceinline__ void d4_add(D4& a, const float4 v) { a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+__device__ __forceinline__ void d4_add(D4& a, const D4& v) { a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+__device__ __forceinline__ bool last_block_fold(int* __restrict__ tickets, const float* __restrict__ partial, int C4, int TX,
+                                                int TY, D4& s, D4& q) {
+  __shared__ int is_last;
+  __shared__ D4 red[2][BN_TPB];
+  const int tx = threadIdx.x & (TX - 1), ty = threadIdx.x / TX, c4 = blockIdx.x * TX + tx;
+  const int nblk = gridDim.y;
+  const int64_t C = (int64_t)C4 * 4;
+  if (nblk > 1) {
+    __threadfence();                   // this work-group's partial rows are visible device-wide ...
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int t = __hip_atomic_fetch_add(tickets + blockIdx.x, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      is_last = t == nblk - 1;
     }
-  red[0][g][lc] = s;
-  red[1][g][lc] = q;
+    __syncthreads();
+    if (!is_last) return false;
+    __threadfence();                   // ... and everybody else's to this one
+  }
+  s = D4{0.0, 0.0, 0.0, 0.0}; q = s;
+  for (int b = ty; b < nblk; b += TY) {
+    d4_add(s, ld4(partial + (int64_t)b * 2 * C, c4));
+    d4_add(q, ld4(partial + (int64_t)b * 2 * C + C, c4));
+  }
+  red[0][threadIdx.x] = s;
+  red[1][threadIdx.x] = q;
   __syncthreads();
-  if (g != 0 || c >= C) return false;
-  for (int k = 1; k < FIN_G; ++k) { s += red[0][k][lc]; q += red[1][k][lc]; }
+  if (threadIdx.x == 0 && nblk > 1) __hip_atomic_store(tickets + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (ty != 0) return false;
+  for (int k = 1; k < TY; ++k) { d4_add(s, red[0][k * TX + tx]); d4_add(q, red[1][k * TX + tx]); }
   return true;
-}
-
-// packed[0..C) = mean, packed[C..2C) = biased variance, packed[2C] = M     (what one rank contributes)
-__global__ void __launch_bounds__(BN_TPB)
-k_stats_finalize(const float* __restrict__ x, const float* __restrict__ partial, int nblk, int64_t M, int C,
-                 float* __restrict__ packed) {
-  int c;
-  double s, q;
-  if (!finalize_sums(partial, nblk, C, c, s, q)) return;
-  const double n = (double)M;
-  const double ms = s / n;
-  packed[c] = (float)((double)x[c] + ms);
-  packed[C + c] = (float)fmax(q / n - ms * ms, 0.0);
-  if (c == 0) packed[2 * C] = (float)M;
 }
 
 // Count-weighted merge of the ranks' statistics for one channel (batch_norm_gather_stats_with_counts), in double.
@@ -229,8 +242,9 @@ k_apply(const float* __restrict__ gathered, int W, const float* __restrict__ wei
 template <int MODE>
 __global__ void __launch_bounds__(BN_TPB)
 k_bwd_reduce(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ y,
-             const float* __restrict__ scale_shift, const float* __restrict__ mean, float* __restrict__ partial,
-             int64_t M, int C4, int TX, int TY) {
+             const float* __restrict__ scale_shift, const float* __restrict__ mean, const float* __restrict__ invstd,
+             int* __restrict__ tickets, float* __restrict__ partial, float* __restrict__ sums, float* __restrict__ grad_weight,
+             float* __restrict__ grad_bias, int64_t M, int C4, int TX, int TY) {
   __shared__ float4 sh[2 * BN_TPB];
   float4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
   const int cc = blockIdx.x * TX + (threadIdx.x & (TX - 1));
@@ -245,26 +259,26 @@ k_bwd_reduce(const float* __restrict__ dy, const float* __restrict__ x, const fl
   BN_ROWS(BODY)
 #undef BODY
   block_rows_sum(s, q, TX, TY, sh);
+  const int64_t C = (int64_t)C4 * 4;
   if (ty == 0) {
-    const int64_t C = (int64_t)C4 * 4;
     float* p = partial + (int64_t)blockIdx.y * 2 * C;
     st4(p, c4, s);
     st4(p + C, c4, q);
   }
-}
-
-// sums[0..C) = sum dz, sums[C..2C) = sum dz (x - mean)   (this rank); grad_weight = sums[C+c] * invstd, grad_bias
-__global__ void __launch_bounds__(BN_TPB)
-k_bwd_finalize(const float* __restrict__ partial, int nblk, int C, const float* __restrict__ invstd,
-               float* __restrict__ sums, float* __restrict__ grad_weight, float* __restrict__ grad_bias) {
-  int c;
-  double sd, qd;
-  if (!finalize_sums(partial, nblk, C, c, sd, qd)) return;
-  const float s = (float)sd, q = (float)qd;
-  sums[c] = s;
-  sums[C + c] = q;
-  if (grad_weight) grad_weight[c] = q * invstd[c];
-  if (grad_bias) grad_bias[c] = s;
+  // the last work-group of the chunk: sums[0..C) = sum dz, sums[C..2C) = sum dz (x - mean)  (this rank);
+  // grad_weight = sums[C + c] * invstd[c], grad_bias = sums[c]
+  D4 ds, dq;
+  if (!last_block_fold(tickets, partial, C4, TX, TY, ds, dq)) return;
+  const float sv[4] = {(float)ds.x, (float)ds.y, (float)ds.z, (float)ds.w};
+  const float qv[4] = {(float)dq.x, (float)dq.y, (float)dq.z, (float)dq.w};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = 4 * c4 + k;
+    sums[c] = sv[k];
+    sums[C + c] = qv[k];
+    if (grad_weight) grad_weight[c] = qv[k] * invstd[c];
+    if (grad_bias) grad_bias[c] = sv[k];
+  }
 }
 
 // dx = (dz - sum_dz/n - (x - mean) * invstd^2 * sum_dz_xmu/n) * invstd * w        (batch_norm_backward_elemt)
@@ -313,17 +327,18 @@ k_bwd_apply(const float* __restrict__ dy, const float* __restrict__ x, const flo
 
 }  // namespace
 
+// workspace: BN_HDR int32 tickets (zero on entry, left zero), then the [gy][2][C] partial rows
 size_t bn_workspace_floats(int64_t M, int C) {
   const BnTile t = bn_tile(M, C / 4, CAP_MAX);
-  return (size_t)t.gy * 2 * C;
+  if (t.gx > BN_HDR) return 0;         // more channel chunks than tickets (C > 4096 with an odd C / 4): unsupported
+  return (size_t)BN_HDR + (size_t)t.gy * 2 * C;
 }
 
 int run_bn_stats(const float* x, int64_t M, int C, float* ws, float* packed, hipStream_t st) {
   const BnTile t = bn_tile(M, C / 4, bn_caps().stats);
-  hipLaunchKernelGGL(k_stats, dim3(t.gx, t.gy), dim3(BN_TPB), 0, st, x, ws, M, C / 4, t.TX, t.TY);
+  hipLaunchKernelGGL(k_stats, dim3(t.gx, t.gy), dim3(BN_TPB), 0, st, x, reinterpret_cast<int*>(ws), ws + BN_HDR, packed, M,
+                     C / 4, t.TX, t.TY);
   CHECKED("k_stats");
-  hipLaunchKernelGGL(k_stats_finalize, dim3((C + FIN_CH - 1) / FIN_CH), dim3(BN_TPB), 0, st, x, ws, t.gy, M, C, packed);
-  CHECKED("k_stats_finalize");
   return PIXPRO_OK;
 }
 
@@ -351,7 +366,8 @@ int run_bn_bwd_reduce(const float* dy, const float* x, const float* y, const flo
                       float* grad_bias, hipStream_t st) {
   const BnTile t = bn_tile(M, C / 4, bn_caps().bwd_reduce);
   const dim3 g(t.gx, t.gy), b(BN_TPB);
-#define REDUCE(MD) hipLaunchKernelGGL((k_bwd_reduce<MD>), g, b, 0, st, dy, x, y, scale_shift, mean, ws, M, C / 4, t.TX, t.TY)
+#define REDUCE(MD) hipLaunchKernelGGL((k_bwd_reduce<MD>), g, b, 0, st, dy, x, y, scale_shift, mean, invstd,                \
+                                     reinterpret_cast<int*>(ws), ws + BN_HDR, sums, grad_weight, grad_bias, M, C / 4, t.TX, t.TY)
   switch (mask_mode(relu, scale_shift)) {
     case 0: REDUCE(0); break;
     case 1: REDUCE(1); break;
@@ -359,9 +375,6 @@ int run_bn_bwd_reduce(const float* dy, const float* x, const float* y, const flo
   }
 #undef REDUCE
   CHECKED("k_bwd_reduce");
-  hipLaunchKernelGGL(k_bwd_finalize, dim3((C + FIN_CH - 1) / FIN_CH), dim3(BN_TPB), 0, st, ws, t.gy, C, invstd, sums, grad_weight,
-                     grad_bias);
-  CHECKED("k_bwd_finalize");
   return PIXPRO_OK;
 }
 

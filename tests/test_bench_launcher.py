@@ -49,3 +49,23 @@ def test_a_failing_rank_fails_the_launch():
 def test_too_few_gpus_is_refused():
     r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"])   # no GPU here and no rehearsal flag
     assert r.returncode != 0 and "GPU(s) visible" in r.stderr      # every rank checks for itself; the parent asks nothing
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_two_rank_rehearsal_runs_the_real_step(dev):
+    """The N > 1 control flow of the REAL bench step on the one-GPU box the driver uses: two ranks share
+    the GPU and talk over gloo (PIXPRO_REHEARSAL=1) - DDP gradient buckets, the fused SyncBN statistics exchange, shard
+    seeds, barrier + max-over-ranks timing, and the SyncBN A/B that a multi-GPU run appends.  Never a measurement."""
+    r = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "8", "--arch", "resnet18", "--no-cpu-baseline"],
+             {"PIXPRO_REHEARSAL": "1"}, timeout=850)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["config"]["global_batch"] == 16
+    assert out["rccl"]["world"] == 2 and out["rccl"]["backend"] == "gloo" and out["rccl"]["allreduce_of_ones"] == 2
+    assert "rehearsal" in out["config"] and out["value"] > 0
+    ab = out["rccl"]["syncbn_ab"]
+    assert ab["default"] > 0 and ab["bn_view_batch"] > 0 and "key_bn_group+second_stream" not in ab
+    assert out["hot_kernels"]["ppm_loss"]["ms_per_launch"] > 0

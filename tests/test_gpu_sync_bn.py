@@ -379,3 +379,62 @@ def test_model_step_with_view_batching_matches_two_passes(dev):
     assert out[0][6] == out[1][6] == 2
     with pytest.raises(ValueError, match="needs --fused-bn"):
         pixpro_mod.PixPro(resnet.resnet18, types.SimpleNamespace(**{**vars(margs), "fused_bn": False}))
+
+
+def test_flush_counters_makes_buffer_walks_current(dev):
+    """`num_batches_tracked` is incremented lazily; readers that walk buffers() directly must call
+    sync_bn.flush_counters first (attribute access and state_dict flush by themselves)."""
+    from contrast.sync_bn import FusedSyncBatchNorm, flush_counters
+    net = torch.nn.Sequential(FusedSyncBatchNorm(8), FusedSyncBatchNorm(8)).to(dev).train()
+    x = torch.randn(4, 8, 5, 5, device=dev).contiguous(memory_format=CL)
+    for _ in range(3):
+        net(x)
+    stale = [int(b) for n, b in net.named_buffers() if n.endswith("num_batches_tracked")]
+    assert stale == [0, 0]                                  # the documented limitation
+    flush_counters(net)
+    assert [int(b) for n, b in net.named_buffers() if n.endswith("num_batches_tracked")] == [3, 3]
+    net(x)
+    assert int(net.state_dict()["1.num_batches_tracked"]) == 4
+
+
+def test_last_block_fold_is_repeatable_and_stream_safe(dev):
+    """Round 4: the partial sums of bn_stats / bn_backward_reduce are folded by the work-group that draws the last ticket of
+    its channel chunk (no finalize launches).  Which work-group that is varies from launch to launch; the result must
+    not: 40 forward+backward passes over the same tensors agree bit for bit, also when two streams run different layers at
+    the same time (each stream owns its ticket workspace), and the tickets are left at zero."""
+    from contrast import _native as nv
+    from contrast.sync_bn import FusedSyncBatchNorm
+    g = torch.Generator().manual_seed(11)
+    shapes = [(64, 64, 56, 56), (32, 256, 28, 28), (16, 2048, 7, 7), (3, 12, 5, 7)]
+    layers = []
+    for shp in shapes:
+        bn = FusedSyncBatchNorm(shp[1]).to(dev).train()
+        x = torch.randn(*shp, generator=g).to(dev).contiguous(memory_format=CL)
+        dy = torch.randn(*shp, generator=g).to(dev).contiguous(memory_format=CL)
+        layers.append((bn, x, dy))
+
+    def run(bn, x, dy):
+        xf = x.clone().requires_grad_(True)
+        y = bn(xf, None, True)
+        y.backward(dy)
+        return y.detach().clone(), xf.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone()
+
+    first = []
+    for bn, x, dy in layers:
+        first.append(run(bn, x, dy))
+        bn.zero_grad()
+    side = torch.cuda.Stream(device=dev)
+    for it in range(40):
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            got_side = [run(*layers[i]) for i in (1, 3)]
+        got_main = [run(*layers[i]) for i in (0, 2)]
+        torch.cuda.current_stream().wait_stream(side)
+        for i, got in zip((1, 3, 0, 2), got_side + got_main):
+            for a, b in zip(got, first[i]):
+                assert torch.equal(a, b), f"iteration {it}, layer {i}"
+            layers[i][0].zero_grad()
+    torch.cuda.synchronize()
+    for buf in nv._zeroed.values():
+        assert int(buf[:4096].view(torch.int32).abs().sum()) == 0          # every ticket back at zero
+    assert len(nv._zeroed) >= 2                                           # one workspace per stream

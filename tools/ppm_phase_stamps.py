@@ -9,15 +9,18 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "pixpro-with-opticalflow_amd")
 sys.path.insert(0, PKG)
-import torch  # noqa: E402
+torch = None
 
+NAMES_NHWC = ["start", "wait x (top barrier)", "v dma, pts, S gemm", "v wait, barrier, k dma", "rx, maskbits", "rv norms", "S epilogue",
+              "Y gemm + edge", "ny, rk", "G gemm + edge", "loss reduce", "dY, barrier", "dA gemm + epi", "dV gemm + edge",
+              "dV reduce", "x dma, dv epi, barrier", "dv store, symm", "x wait, barrier", "dX gemm + edge", "dX reduce",
+              "next-x dma, dx epi, barrier", "dx store"]
 NAMES = ["start", "load x, tap issue", "S gemm, pts, v->LDS", "rx, maskbits", "rv norms, S epi", "Y gemm", "ny, rk, Yhat", "G gemm", "loss",
          "dY", "dA gemm+epi", "symm", "dV gemm+epi", "store dv", "dX gemm+epi", "store dx"]
 
 
-def main():
-    out = "/tmp/libpixpro_hip_stamps.so"
-    srcs = [os.path.join(PKG, "csrc", f) for f in ("capi.hip", "ppm_fused.hip", "ppm_generic.hip", "ppm_tiled.hip", "flow_prep.hip",
+def build(out):
+    srcs = [os.path.join(PKG, "csrc", f) for f in ("capi.hip", "ppm_fused.hip", "ppm_fused_nhwc.hip", "ppm_generic.hip", "ppm_tiled.hip", "flow_prep.hip",
                                                    "multi_tensor.hip", "sync_bn.hip", "raft_corr.hip")]
     objs = []
     base = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off",
@@ -28,13 +31,34 @@ def main():
         objs.append(o)
     subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-fgpu-rdc", "--hip-link", "-shared", "-fPIC", "-o", out]
                    + objs, check=True)
+
+
+def main():
+    # --build-only PATH: compile the stamped library (no GPU needed; e.g. into exp_libs/, which travels with gpurun);
+    # --lib PATH: use a prebuilt one instead of compiling on the GPU box
+    if "--build-only" in sys.argv:
+        out = sys.argv[sys.argv.index("--build-only") + 1]
+        os.makedirs(os.path.dirname(os.path.abspath(out)), exist_ok=True)
+        build(out)
+        return
+    if "--lib" in sys.argv:
+        out = os.path.abspath(sys.argv[sys.argv.index("--lib") + 1])
+    else:
+        out = "/tmp/libpixpro_hip_stamps.so"
+        build(out)
+    global torch
+    import torch
     from contrast import _native
     _native.LIB_PATH = out
     from contrast import ops
     dev = torch.device("cuda:0")
     N, C, G = 256, 256, 7
     gen = torch.Generator(device=dev).manual_seed(0)
-    t = lambda: torch.randn(N, C, G, G, device=dev, generator=gen)
+    nhwc = "--nhwc" in sys.argv
+    if "--batch" in sys.argv:
+        N = int(sys.argv[sys.argv.index("--batch") + 1])
+    mf = torch.channels_last if nhwc else torch.contiguous_format
+    t = lambda: torch.randn(N, C, G, G, device=dev, generator=gen).contiguous(memory_format=mf)
     x1, v1, x2, v2, k1, k2 = (t() for _ in range(6))
     for z in (x1, v1, x2, v2):
         z.requires_grad_(True)
@@ -51,6 +75,13 @@ def main():
     torch.cuda.synchronize()
     buf = (ctypes.c_ulonglong * 64)()
     assert _native.load().pixpro_debug_stamps(buf) == 0
+    if nhwc:
+        st = list(buf)[32:54]
+        tot = st[-1] - st[0]
+        print(f"NHWC kernel, last item of the last work-group (N={N}): total ticks {tot}")
+        for i in range(1, len(st)):
+            print(f"{NAMES_NHWC[i]:>28s} {st[i] - st[i - 1]:8d} {100.0 * (st[i] - st[i - 1]) / tot:5.1f}%")
+        return
     st = list(buf)[:16]
     tot = st[15] - st[0]
     print(f"total ticks {tot} (s_memtime, 100 MHz const clock? -> {tot / 100:.1f} us if so)")
