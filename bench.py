@@ -712,7 +712,8 @@ def syncbn_ab(a, model, optimizer, scheduler, args, loader, world, dev, rank):
     out = {}
 
     def run(name):
-        it = iter(loader)
+        import itertools
+        it = itertools.cycle(loader.batches)        # the loader itself only holds the headline's steps
         for _ in range(3):
             main_pretrain.train_step(model, optimizer, scheduler, next(it), args)
         el, _ = timed_steps(lambda: main_pretrain.train_step(model, optimizer, scheduler, next(it), args), 5, world, dev)

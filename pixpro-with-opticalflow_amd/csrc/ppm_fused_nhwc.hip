@@ -17,8 +17,8 @@
 //   * The walk is persistent: grid = min(items, CUs); while a work-group finishes item b (dX product, dx store) the x
 //     tile of item b + grid is already travelling into the other tile buffer, so only the first item of a work-group
 //     pays the tile latency in front of its first product.
-//   * dS lives in place of D, and dS + dS^T is formed in place too (two P x P matrices instead of three), which is what
-//     pays for the wider tile rows.
+//   * dS lives in place of D, and dS + dS^T goes where A was once the dV product has read it (two P x P matrices
+//     instead of three), which is what pays for the wider tile rows.
 //
 // Buffers over time (T0, T1 swap roles after every item):
 //   T0: x (S) -> k (G) -> dY (dA, dV) -> x (dX, dx out)         T1: v (Y, dA, dv out) -> x of the next item
@@ -33,7 +33,7 @@ namespace pixpro {
 extern __device__ unsigned long long g_stamps[64];            // defined in ppm_fused.hip; this kernel uses entries 32..63
 #define STAMPN(i)                                                                                  \
   do {                                                                                             \
-    if (stamp_on && threadIdx.x == 0) g_stamps[32 + (i)] = __builtin_amdgcn_s_memtime();            \
+    if (stamp_on >= 0 && threadIdx.x == 0) g_stamps[stamp_on + (i)] = __builtin_amdgcn_s_memtime(); \
   } while (0)
 #else
 #define STAMPN(i)
@@ -50,6 +50,19 @@ constexpr int TILE = TROWS * TS;         // 14,144 floats = 56,576 B
 constexpr int LR = 52;                   // rows of the P x P matrices
 constexpr int KS = LR / 4;               // k-steps over the pixel dimension
 
+// Lane coordinates of a thread.  Inside the persistent loop they are re-derived from an OPAQUE copy of threadIdx.x once per
+// item (lane_ctx): whatever is computed from them - every LDS address of the body - then cannot be hoisted out of the loop,
+// where it would stay live across the whole item (the inlined loop compiled to 256 VGPRs plus spills that way).
+struct Ctx {
+  int tid, wave, lane, lr, lq;
+};
+__device__ __forceinline__ Ctx lane_ctx() {
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  Ctx c;
+  c.tid = tid; c.wave = __builtin_amdgcn_readfirstlane(tid >> 6); c.lane = tid & 63; c.lr = c.lane & 15; c.lq = c.lane >> 4;
+  return c;
+}
 __device__ __forceinline__ int swz(int p) { return (p >> 2) & 3; }
 // element (pixel p, channel c) of a tile
 __device__ __forceinline__ int tix(int p, int c) { return p * TS + ((((c >> 2) ^ swz(p))) << 2) + (c & 3); }
@@ -57,12 +70,14 @@ __device__ __forceinline__ int tix(int p, int c) { return p * TS + ((((c >> 2) ^
 struct Smem {
   float* T;      // [2][TILE]
   float* AA;     // [LR][LS]   A = pow(clamp(S))
-  float* DM;     // [LR][LS]   dA/dS, then dS (in place), then dS + dS^T (in place)
+  float* DM;     // [LR][LS]   dA/dS, then dS (in place); dS + dS^T goes to AA once the dV contraction has read A
   float* rx;     // [64] reciprocal column norms of x and v
   float* rv;
   float* nx2;    // [64] diag of the raw Gram matrix
-  float* part0;  // [NWAVES][64] x2: scratch of the column reductions, used alternately
+  float* part0;  // [NWAVES][64] x3: scratch of the column reductions (rv / k norms / dV; Y norms / dX; loss)
   float* part1;
+  float* part2;
+  float* rkw;    // [NWAVES][64] every wave's own copy of 1 / ||k_j||
   float* qx;     // [64] each
   float* qy;
   float* kx;
@@ -71,7 +86,7 @@ struct Smem {
   unsigned long long* mbits;  // [64]
   int* valid;    // [64]
 };
-constexpr size_t SMEM_FLOATS = 2 * TILE + 2 * LR * LS + 3 * 64 + 2 * NWAVES * 64 + 4 * 64 + 32 + 2 * 64 + 64;
+constexpr size_t SMEM_FLOATS = 2 * TILE + 2 * LR * LS + 3 * 64 + 4 * NWAVES * 64 + 4 * 64 + 32 + 2 * 64 + 64;
 
 __device__ __forceinline__ Smem carve(float* base) {
   Smem s;
@@ -80,7 +95,7 @@ __device__ __forceinline__ Smem carve(float* base) {
   s.AA = p; p += LR * LS;
   s.DM = p; p += LR * LS;
   s.rx = p; p += 64; s.rv = p; p += 64; s.nx2 = p; p += 64;
-  s.part0 = p; p += NWAVES * 64; s.part1 = p; p += NWAVES * 64;
+  s.part0 = p; p += NWAVES * 64; s.part1 = p; p += NWAVES * 64; s.part2 = p; p += NWAVES * 64; s.rkw = p; p += NWAVES * 64;
   s.qx = p; p += 64; s.qy = p; p += 64; s.kx = p; p += 64; s.ky = p; p += 64;
   s.misc = p; p += 32;
   s.mbits = (unsigned long long*)p; p += 2 * 64;
@@ -90,8 +105,8 @@ __device__ __forceinline__ Smem carve(float* base) {
 
 // HBM [P][C] -> LDS tile by LDS-DMA: wave w copies pixel rows w, w + 8, ...; lane l fetches logical chunk l ^ swz(p) into
 // chunk position l.  Nothing orders the copy against LDS reads except s_waitcnt vmcnt + a barrier (tile_landed).
-__device__ __forceinline__ void tile_dma(const float* __restrict__ g, float* T) {
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+__device__ __forceinline__ void tile_dma(const Ctx& cx, const float* __restrict__ g, float* T) {
+  const int wave = cx.wave, lane = cx.lane;
 #pragma unroll
   for (int i = 0; i < 7; ++i) {
     const int p = wave + NWAVES * i;
@@ -99,8 +114,8 @@ __device__ __forceinline__ void tile_dma(const float* __restrict__ g, float* T) 
   }
 }
 // LDS tile -> HBM [P][C], 16 B per lane, one pixel row per wave instruction
-__device__ __forceinline__ void tile_store(float* __restrict__ g, const float* T) {
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+__device__ __forceinline__ void tile_store(const Ctx& cx, float* __restrict__ g, const float* T) {
+  const int wave = cx.wave, lane = cx.lane;
 #pragma unroll
   for (int i = 0; i < 7; ++i) {
     const int p = wave + NWAVES * i;
@@ -110,8 +125,8 @@ __device__ __forceinline__ void tile_store(float* __restrict__ g, const float* T
 }
 
 // 1 / max(||T[:, j]||, 1e-12)-style column sums of squares: lane = pixel, wave w covers channels 32 w .. 32 w + 31
-__device__ __forceinline__ float col_sumsq_part(const float* T) {
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+__device__ __forceinline__ float col_sumsq_part(const Ctx& cx, const float* T) {
+  const int wave = cx.wave, lane = cx.lane;
   const int p = min(lane, P - 1), s = swz(p);
   const float* row = T + p * TS;
   float a0 = 0.f, a1 = 0.f;
@@ -127,8 +142,9 @@ __device__ __forceinline__ float col_sumsq_part(const float* T) {
 // One 16 x 16 tile (ti, tj) of L^T R over K = C, both operands k-contiguous: lane (pixel lr, k group lq) reads the four
 // channels 16 g + 4 lq .. + 3 of its pixel with ONE ds_read_b128 per operand and feeds four MFMA steps (the order of the
 // contraction index is free as long as both operands agree).  Two interleaved accumulators; groups requested four ahead.
-__device__ __forceinline__ f32x4 gemm_pp_tile128(const float* __restrict__ L, const float* __restrict__ R, int ti, int tj) {
-  const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
+__device__ __forceinline__ f32x4 gemm_pp_tile128(const Ctx& cx, const float* __restrict__ L, const float* __restrict__ R, int ti,
+                                              int tj) {
+  const int lr = cx.lr, lq = cx.lq;
   const int pa = min(16 * ti + lr, P - 1), pb = min(16 * tj + lr, P - 1);      // rows beyond P: clamped duplicates, masked later
   const float* la = L + pa * TS + 4 * (lq ^ swz(pa));
   const float* rb = R + pb * TS + 4 * (lq ^ swz(pb));
@@ -167,9 +183,9 @@ __device__ __forceinline__ f32x4 gemm_pp_tile128(const float* __restrict__ L, co
   return acc;
 }
 // Two tiles at once (dA on the padded 4 x 4 grid: tiles `wave` and `wave + 8`), one accumulator each
-__device__ __forceinline__ void gemm_pp_pair128(f32x4& acc0, f32x4& acc1, const float* __restrict__ L,
+__device__ __forceinline__ void gemm_pp_pair128(const Ctx& cx, f32x4& acc0, f32x4& acc1, const float* __restrict__ L,
                                                 const float* __restrict__ R, int t0, int t1) {
-  const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
+  const int lr = cx.lr, lq = cx.lq;
   const int pa0 = min(16 * (t0 >> 2) + lr, P - 1), pb0 = min(16 * (t0 & 3) + lr, P - 1);
   const int pa1 = min(16 * (t1 >> 2) + lr, P - 1), pb1 = min(16 * (t1 & 3) + lr, P - 1);
   const float* la = L + pa0 * TS + 4 * (lq ^ swz(pa0));
@@ -206,47 +222,47 @@ __device__ __forceinline__ void gemm_pp_pair128(f32x4& acc0, f32x4& acc1, const 
   }
 }
 
-// Column 48 of a C x P product on the vector ALU: e(c) = sum_{k < 49} T[k][c] w[k] for the wave's 32 rows.  Lane l takes
-// row (l & 31) of the wave's row list and half of k (l >> 5); w[k] is written by lane k into the wave's own 64-float LDS
-// slice first (same wave writes and reads: no barrier).  Returns e in lanes 0..31 (duplicated in 32..63).
-__device__ __forceinline__ float edge_column(const float* __restrict__ T, float wl, float* __restrict__ ws) {
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int rl = lane & 31, hi = lane >> 5;
-  const int row = 16 * (wave + NWAVES * (rl >> 4)) + (rl & 15);
-  ws[lane] = wl;                            // lanes >= 49 pass 0
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  const float* w = ws + 25 * hi;
-  float e0 = 0.f, e1 = 0.f;
+// C x P contraction on three column tiles with column 48 riding along on the vector ALU: the A values a lane loads for the
+// MFMAs - element (row 16 (wave + 8 m) + lr, k = 4 ks + lq), already scaled - are exactly what the 49th column needs, so it
+// costs one more B value per k-step (fe(ks) = B[k][48]) and MT FMAs, hidden between the MFMAs, instead of a pass of its own
+// over the tile.  e[m] comes back summed over the four k groups: every lane holds the value of row 16 (wave + 8 m) + lr.
+template <class FA, class FS, class FB, class FE>
+__device__ __forceinline__ void gemm_cp_e(f32x4 (&acc)[MT][NTM], float (&e)[MT], FA fa, FS fs, FB fb, FE fe) {
+  float a[MT], b[NTM], sc, be;
 #pragma unroll
-  for (int k = 0; k < 24; k += 2) {
-    e0 = __builtin_fmaf(T[tix(25 * hi + k, row)], w[k], e0);
-    e1 = __builtin_fmaf(T[tix(25 * hi + k + 1, row)], w[k + 1], e1);
-  }
-  e0 = __builtin_fmaf(hi ? 0.f : T[tix(24, row)], w[24], e0);     // k = 24: lower half only (the upper half ends at 48 = 25 + 23)
-  float e = e0 + e1;
-  e += __shfl_xor(e, 32, 64);
-  return e;
-}
-// The same for G = k_hat M^T: w[k] = M[48][k] / ||k_k|| is zero except for the few positive pairs of row 48, so the
-// loop runs over the set bits of the row (wave-uniform).
-__device__ __forceinline__ float edge_column_bits(const float* __restrict__ T, unsigned long long bits,
-                                                  const float* __restrict__ rk) {
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int rl = lane & 31;
-  const int row = 16 * (wave + NWAVES * (rl >> 4)) + (rl & 15);
-  unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)bits), hi = __builtin_amdgcn_readfirstlane((unsigned)(bits >> 32));
-  float e0 = 0.f, e1 = 0.f;
-  while (lo | hi) {
-    int k;
-    if (lo) { k = __builtin_ctz(lo); lo &= lo - 1; } else { k = 32 + __builtin_ctz(hi); hi &= hi - 1; }
-    e0 = __builtin_fmaf(T[tix(k, row)], rk[k], e0);
-    if (lo | hi) {
-      if (lo) { k = __builtin_ctz(lo); lo &= lo - 1; } else { k = 32 + __builtin_ctz(hi); hi &= hi - 1; }
-      e1 = __builtin_fmaf(T[tix(k, row)], rk[k], e1);
+  for (int m = 0; m < MT; ++m) { a[m] = fa(m, 0); e[m] = 0.f; }
+#pragma unroll
+  for (int n = 0; n < NTM; ++n) b[n] = fb(n, 0);
+  sc = fs(0); be = fe(0);
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    float an[MT], bn[NTM], scn, ben;
+    const int kn = ks + 1 < KS ? ks + 1 : ks;          // last step re-reads its own operands (never used)
+#pragma unroll
+    for (int m = 0; m < MT; ++m) an[m] = fa(m, kn);
+#pragma unroll
+    for (int n = 0; n < NTM; ++n) bn[n] = fb(n, kn);
+    scn = fs(kn); ben = fe(kn);
+    __builtin_amdgcn_sched_barrier(0);                 // keep the requests above ahead of the MFMAs below
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const float am = a[m] * sc;
+      e[m] = __builtin_fmaf(am, be, e[m]);
+#pragma unroll
+      for (int n = 0; n < NTM; ++n) acc[m][n] = mfma16(am, b[n], acc[m][n]);
     }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) a[m] = an[m];
+#pragma unroll
+    for (int n = 0; n < NTM; ++n) b[n] = bn[n];
+    sc = scn; be = ben;
   }
-  return e0 + e1;
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    e[m] += __shfl_xor(e[m], 16, 64);
+    e[m] += __shfl_xor(e[m], 32, 64);
+  }
 }
 
 typedef const pixpro_problem __attribute__((address_space(4))) * pb_kernarg_t;
@@ -267,15 +283,33 @@ __device__ __forceinline__ T kernarg_load(const T __attribute__((address_space(4
 // 256 VGPRs plus spills); as a function the body is allocated like a straight-line kernel.  pb / D are read from the
 // kernel-argument segment (scalar loads), the LDS carve is recomputed from the dynamic LDS base.  `flip` selects which
 // tile buffer plays T0 for this item.
+// The flow taps of the NEXT item, requested by wave 0 while the current item finishes and never used as values: the
+// loads pull the lines into the cache hierarchy (and the crop records into the scalar cache), so that the real
+// displace_fetch at the top of the next item - a chain of two dependent round trips that nothing hides once the x tile is
+// prefetched - finds them near.  The registers stay reserved until the next item has waited for them.
+struct Warm {
+  float v[8];
+  unsigned m;
+};
+
+#ifndef NHWC_CALL_BODY
+#define NHWC_CALL_BODY 0     // 1: the item body as a non-inlined function (kept for comparison: costs ~60 callee-saved VGPR spills)
+#endif
+#if NHWC_CALL_BODY
 __device__ __attribute__((noinline)) void nhwc_item(pb_kernarg_t pbp, dirs_kernarg_t Dp, float* __restrict__ loss_n,
                                                      float* __restrict__ pos_num, float* __restrict__ pos_mean, int b,
                                                      int nitems, int flip) {
-  extern __shared__ __attribute__((aligned(16))) float smem_raw[];
   const pixpro_problem pb = kernarg_load<pixpro_problem>(pbp);
+#else
+__device__ __forceinline__ void nhwc_item(const pixpro_problem& pb, dirs_kernarg_t Dp, float* __restrict__ loss_n,
+                                          float* __restrict__ pos_num, float* __restrict__ pos_mean, int b, int nitems,
+                                          int flip, Warm& warm) {
+#endif
+  extern __shared__ __attribute__((aligned(16))) float smem_raw[];
   const Smem sm = carve(smem_raw);
   const int N = pb.N;
-  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lr = lane & 15,
-            lq = lane >> 4;
+  const Ctx cx = lane_ctx();
+  const int tid = cx.tid, wave = cx.wave, lane = cx.lane, lr = cx.lr, lq = cx.lq;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   constexpr int tile = C * P;
   // A operand of the C x P products: element (channel 16 (wave + 8 m) + lr, pixel k = 4 ks + lq).  swz(k) = ks & 3 is
@@ -286,12 +320,15 @@ __device__ __attribute__((noinline)) void nhwc_item(pb_kernarg_t pbp, dirs_kerna
   // one 16-B chunk of the pixel's row
   auto c_at = [&](int m, int nn) { return tix(16 * nn + lr, 16 * (wave + NWAVES * m) + 4 * lq); };
   auto crow = [&](int m, int r) { return 16 * (wave + NWAVES * m) + 4 * lq + r; };
-  const int erow = 16 * (wave + NWAVES * ((lane & 31) >> 4)) + (lane & 15);     // row of this lane's edge value (lanes 0..31)
-  const bool elive = lane < 32;
+  // column 48 lives outside the MFMA tile grid: value e[m] of row erow(m), the same in the four lanes lr, lr + 16, ...; the
+  // lanes below 16 speak for it in sums and stores
+  auto erow = [&](int m) { return 16 * (wave + NWAVES * m) + lr; };
+  const bool elive = lane < 16;
   float* T0 = sm.T + (flip ? TILE : 0);
   float* T1 = sm.T + (flip ? 0 : TILE);
 #ifdef PIXPRO_STAMPS
-  const bool stamp_on = blockIdx.x == gridDim.x - 1 && b + (int)gridDim.x >= nitems;     // the work-group's last item
+  // the last work-group stamps its first item into entries 0.. and its last item into entries 32..
+  const int stamp_on = blockIdx.x != gridDim.x - 1 ? -1 : b + (int)gridDim.x >= nitems ? 32 : b == (int)blockIdx.x ? 0 : -1;
 #endif
   STAMPN(0);
 
@@ -307,9 +344,13 @@ __device__ __attribute__((noinline)) void nhwc_item(pb_kernarg_t pbp, dirs_kerna
   // x has landed in T0 (requested before the loop / during the previous item); every wave is done with the previous
   // item's tiles
   wait_vm<0>();
+#if !NHWC_CALL_BODY
+  asm volatile("" ::"v"(warm.v[0]), "v"(warm.v[1]), "v"(warm.v[2]), "v"(warm.v[3]), "v"(warm.v[4]), "v"(warm.v[5]),
+               "v"(warm.v[6]), "v"(warm.v[7]), "v"(warm.m));      // the warm-up loads of the previous item's tail have returned
+#endif
   __syncthreads();
   STAMPN(1);
-  tile_dma(gv, T1);                   // v streams in under the S contraction (one tile request at a time)
+  tile_dma(cx, gv, T1);                   // v streams in under the S contraction (one tile request at a time)
 
   // lazy flow mode with a chain (nframe > 2): the nine composed-flow pixels each point needs (common.h) are spread over
   // the work-group, two dependent stages through LDS (the AA matrix is not live yet)
@@ -374,35 +415,34 @@ __device__ __attribute__((noinline)) void nhwc_item(pb_kernarg_t pbp, dirs_kerna
 
   // ---- S_raw = x^T x ; rx from its diagonal ; S, A, D ----
   // S is symmetric and 49 = 48 + 1: the six upper tiles of the 3 x 3 tile grid go to the matrix cores, one per wave
-  // 1..6, and are mirrored by the epilogue; waves 7 and 0 (wave 0 once its sample points are requested) take row 48
-  // (49 dot products over half of C each) on the vector ALU.
+  // 1..6, and are mirrored by the epilogue; wave 7 takes row 48 (49 dot products over C) on the vector ALU; wave 0 has the
+  // sample points (a latency chain: crop records -> flow taps).
   const int sw_ = wave - 1;                                                            // tile of waves 1..6
   const int sti = (sw_ >= 3) + (sw_ >= 5), stj = sw_ - (sw_ >= 3 ? 2 : 0) - (sw_ >= 5 ? 1 : 0);
   const bool stile = wave >= 1 && wave <= 6;
   f32x4 accS = zero4;
   if (stile) {
-    accS = gemm_pp_tile128(T0, T0, sti, stj);
+    accS = gemm_pp_tile128(cx, T0, T0, sti, stj);
     if (sti == stj) {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         if (4 * lq + r == lr) sm.nx2[16 * sti + lr] = accS[r];
     }
-  } else {
-    const int half = wave == 7 ? 0 : 1, jj = min(lane, P - 1), sj = swz(jj);
+  } else if (wave == 7) {
+    const int jj = min(lane, P - 1), sj = swz(jj);
     const float* xj = T0 + jj * TS;
     const float* xe = T0 + (P - 1) * TS;            // swz(48) == 0
-    float e0 = 0.f, e1 = 0.f;
+    float e0 = 0.f, e1 = 0.f, e2 = 0.f, e3 = 0.f;
 #pragma unroll 8
-    for (int q = 0; q < 32; ++q) {
-      const int ql = 32 * half + q;
-      const float4 u = *reinterpret_cast<const float4*>(xe + 4 * ql);
-      const float4 w = *reinterpret_cast<const float4*>(xj + 4 * (ql ^ sj));
+    for (int q = 0; q < 64; ++q) {
+      const float4 u = *reinterpret_cast<const float4*>(xe + 4 * q);
+      const float4 w = *reinterpret_cast<const float4*>(xj + 4 * (q ^ sj));
       e0 = __builtin_fmaf(u.x, w.x, e0); e1 = __builtin_fmaf(u.y, w.y, e1);
-      e0 = __builtin_fmaf(u.z, w.z, e0); e1 = __builtin_fmaf(u.w, w.w, e1);
+      e2 = __builtin_fmaf(u.z, w.z, e2); e3 = __builtin_fmaf(u.w, w.w, e3);
     }
-    sm.part1[half * 64 + lane] = e0 + e1;               // part1 is next used by the Y-norm reduction
+    sm.part1[lane] = (e0 + e1) + (e2 + e3);             // part1 is next used by the Y-norm reduction
   }
-  if (wave == 0) {                 // the sample points: taps requested before the row-48 work
+  if (wave == 0) {                 // the sample points: taps requested above, the threshold search ran under their latency
     if (dense) {
       float ox, oy;
       displace_finish(taps, fgd, ptx, pty, ox, oy, ptv);
@@ -414,15 +454,13 @@ __device__ __attribute__((noinline)) void nhwc_item(pb_kernarg_t pbp, dirs_kerna
     sm.valid[lane] = (live && ptv) ? 1 : 0;
   }
   STAMPN(2);
-  wait_vm<0>();                    // this wave's rows of v have landed ...
-  __syncthreads();                 // ... everybody's; every wave is done with x in T0
-  tile_dma(gk, T0);                // k streams in under the mask / norm / S epilogue / Y phases
+  __syncthreads();                 // every wave is done with x in T0; nx2 / row 48 / the sample points are published
+  tile_dma(cx, gk, T0);            // k streams in under the mask / S epilogue / norm / Y phases
   STAMPN(3);
-  if (tid < 64) {
-    float n2 = sm.nx2[tid < 48 ? tid : 0];
-    if (tid >= 48) n2 = sm.part1[48] + sm.part1[64 + 48];
-    sm.rx[tid] = 1.f / fmaxf(sqrtf(n2), 1e-12f);
-  }
+  // 1 / ||x_j|| from the diagonal of the raw Gram matrix: every lane works out the few it needs (the S epilogue below
+  // runs before the next barrier), lanes 0..63 also publish the vector for the dX contraction
+  auto rxof = [&](int j) { return 1.f / fmaxf(sqrtf(j < 48 ? sm.nx2[j] : sm.part1[48]), 1e-12f); };
+  if (tid < 64) sm.rx[tid] = rxof(min(tid, P - 1));
   // ---- positive-pair bit mask: row i of M = ballot over j (PixPro.py:217-223); row i's point comes out of lane i ----
   {
     const float T = sm.misc[2];     // sqrtf(d2) / diag < pos_ratio  <=>  d2 < T  (dist_threshold)
@@ -443,30 +481,15 @@ __device__ __attribute__((noinline)) void nhwc_item(pb_kernarg_t pbp, dirs_kerna
     if (lane == 0) sm.misc[8 + wave] = (float)cnt_w;
   }
   STAMPN(4);
-  // ---- rv = 1 / ||v_j|| (the two barriers also publish rx, the mask rows and counts)
-  sm.part0[wave * 64 + lane] = col_sumsq_part(T1);
-  __syncthreads();
-  if (tid < 64) {
-    float t = 0.f;
-#pragma unroll
-    for (int w = 0; w < NWAVES; ++w) t += sm.part0[w * 64 + tid];
-    sm.rv[tid] = 1.f / fmaxf(sqrtf(t), 1e-12f);
-  }
-  __syncthreads();
-  STAMPN(5);
-  if (tid == 0) {
-    float c = 0.f;
-    for (int w = 0; w < NWAVES; ++w) c += sm.misc[8 + w];
-    sm.misc[1] = c;                                    // read in the loss phase, several barriers from here
-  }
+  // ---- S epilogue: A = pow(clamp(S)), D = dA/dS (needs nothing of v: it runs while v is still landing)
   if (stile) {
     const int j = 16 * stj + lr;
-    const float rxj = sm.rx[j];
+    const float rxj = rxof(j);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int i = 16 * sti + 4 * lq + r;
       float a, d;
-      pow_map(accS[r] * sm.rx[i] * rxj, pb.p, pb.clamp, a, d);
+      pow_map(accS[r] * rxof(i) * rxj, pb.p, pb.clamp, a, d);
       sm.AA[i * LS + j] = a;
       sm.DM[i * LS + j] = d;
       if (sti != stj) { sm.AA[j * LS + i] = a; sm.DM[j * LS + i] = d; }
@@ -476,7 +499,7 @@ __device__ __attribute__((noinline)) void nhwc_item(pb_kernarg_t pbp, dirs_kerna
     const int t2 = (wave == 7 ? 0 : 64) + lane;      // 0..127
     if (t2 < P) {
       float a, d;
-      pow_map((sm.part1[t2] + sm.part1[64 + t2]) * sm.rx[P - 1] * sm.rx[t2], pb.p, pb.clamp, a, d);
+      pow_map(sm.part1[t2] * rxof(P - 1) * rxof(t2), pb.p, pb.clamp, a, d);
       sm.AA[(P - 1) * LS + t2] = a; sm.DM[(P - 1) * LS + t2] = d;
       sm.AA[t2 * LS + (P - 1)] = a; sm.DM[t2 * LS + (P - 1)] = d;
     }
@@ -489,8 +512,30 @@ __device__ __attribute__((noinline)) void nhwc_item(pb_kernarg_t pbp, dirs_kerna
       sm.AA[i * LS + jz] = 0.f; sm.DM[i * LS + jz] = 0.f;
     }
   }
+  STAMPN(5);
+  // ---- rv = 1 / ||v_j||.  v was requested at the top of the item; its copies are older than the (6 or 7) copies of k this
+  // wave has just issued and copies complete in order, so "at most six outstanding" means v has landed.
+  wait_vm<6>();
+  __syncthreads();                 // v complete in T1 (and A, D, the mask rows, the counts, rx published)
+  sm.part0[wave * 64 + lane] = col_sumsq_part(cx, T1);
   __syncthreads();
+  if (tid < 64) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < NWAVES; ++w) t += sm.part0[w * 64 + tid];
+    sm.rv[tid] = 1.f / fmaxf(sqrtf(t), 1e-12f);
+  }
+  if (tid == 0) {
+    float c = 0.f;
+    for (int w = 0; w < NWAVES; ++w) c += sm.misc[8 + w];
+    sm.misc[1] = c;                                    // read in the loss phase, several barriers from here
+  }
+  wait_vm<0>();                    // this wave's rows of k have landed (requested four phases ago) ...
+  __syncthreads();                 // ... everybody's; rv published
   STAMPN(6);
+  // partial sums of squares of k's columns now (part0 is free again): they are published by the barrier of the Y norms,
+  // which then needs no second barrier for 1 / ||k||
+  if (pb.normalize_k) sm.part0[wave * 64 + lane] = col_sumsq_part(cx, T0);
 
   // ---- Y = v_hat A : three column tiles on the matrix cores, column 48 as a dot product per row (edge_column) ----
   f32x4 Y[MT][NTM];
@@ -498,18 +543,19 @@ __device__ __attribute__((noinline)) void nhwc_item(pb_kernarg_t pbp, dirs_kerna
   for (int m = 0; m < MT; ++m)
 #pragma unroll
     for (int nn = 0; nn < NTM; ++nn) Y[m][nn] = zero4;
-  gemm_cp<MT, NTM>(Y, KS,
-                   [&](int m, int ks) { return a_at(T1, m, ks); },
-                   [&](int ks) { return sm.rv[4 * ks + lq]; },
-                   [&](int nn, int ks) { return sm.AA[(4 * ks + lq) * LS + 16 * nn + lr]; });
-  float Ye = edge_column(T1, lane < P ? sm.rv[lane] * sm.AA[lane * LS + (P - 1)] : 0.f, sm.part0 + wave * 64);
+  float Ye[MT];
+  gemm_cp_e(Y, Ye,
+            [&](int m, int ks) { return a_at(T1, m, ks); },
+            [&](int ks) { return sm.rv[4 * ks + lq]; },
+            [&](int nn, int ks) { return sm.AA[(4 * ks + lq) * LS + 16 * nn + lr]; },
+            [&](int ks) { return sm.AA[(4 * ks + lq) * LS + (P - 1)]; });
   STAMPN(7);
-  // Column norms of Y and of k with two barriers.  Y stays raw in its registers; every wave keeps its own copy of
-  // 1 / ||k_j|| in its slice of part1.
+  // Column norms of Y and of k behind ONE barrier.  Y stays raw in its registers; every wave keeps its own copy of
+  // 1 / ||k_j|| (rkw).
   float ry[NTM];     // 1 / ||Y[:, i]|| of this lane's columns
   float rye = 0.f;   // ... and of column 48
   {
-    const float qe = wave_sum(elive ? Ye * Ye : 0.f);
+    const float qe = wave_sum(elive ? __builtin_fmaf(Ye[0], Ye[0], Ye[1] * Ye[1]) : 0.f);
     if (lane == 0) sm.part1[wave * 64 + 48] = qe;
 #pragma unroll
     for (int nn = 0; nn < NTM; ++nn) {
@@ -522,9 +568,7 @@ __device__ __attribute__((noinline)) void nhwc_item(pb_kernarg_t pbp, dirs_kerna
       q += __shfl_xor(q, 32, 64);
       if (lane < 16) sm.part1[wave * 64 + 16 * nn + lane] = q;
     }
-    wait_vm<0>();                           // this wave's rows of k have landed
-    __syncthreads();                        // ... everybody's
-    if (pb.normalize_k) sm.part0[wave * 64 + lane] = col_sumsq_part(T0);
+    __syncthreads();
 #pragma unroll
     for (int nn = 0; nn < NTM; ++nn) {
       float t = 0.f;
@@ -538,7 +582,6 @@ __device__ __attribute__((noinline)) void nhwc_item(pb_kernarg_t pbp, dirs_kerna
       for (int w = 0; w < NWAVES; ++w) t += sm.part1[w * 64 + 48];
       rye = 1.f / fmaxf(sqrtf(t), 1e-12f);
     }
-    __syncthreads();
     float rkj = 1.f;
     if (pb.normalize_k) {
       float t = 0.f;
@@ -546,7 +589,7 @@ __device__ __attribute__((noinline)) void nhwc_item(pb_kernarg_t pbp, dirs_kerna
       for (int w = 0; w < NWAVES; ++w) t += sm.part0[w * 64 + lane];
       rkj = 1.f / fmaxf(sqrtf(t), 1e-12f);
     }
-    sm.part1[wave * 64 + lane] = rkj;       // wave-private from here to the end of the G contraction
+    sm.rkw[wave * 64 + lane] = rkj;         // wave-private
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
@@ -559,13 +602,16 @@ __device__ __attribute__((noinline)) void nhwc_item(pb_kernarg_t pbp, dirs_kerna
         const float4 o = make_float4(Y[m][nn][0] * ry[nn], Y[m][nn][1] * ry[nn], Y[m][nn][2] * ry[nn], Y[m][nn][3] * ry[nn]);
         *reinterpret_cast<float4*>(gp + (size_t)(16 * nn + lr) * C + crow(m, 0)) = o;
       }
-    if (elive) gp[(size_t)(P - 1) * C + erow] = Ye * rye;
+    if (elive) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m) gp[(size_t)(P - 1) * C + erow(m)] = Ye[m] * rye;
+    }
   }
 
   STAMPN(8);
   // ---- G = k_hat M^T ----
   f32x4 G[MT][NTM];
-  float Ge = 0.f;
+  float Ge[MT];
 #pragma unroll
   for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -578,14 +624,16 @@ __device__ __attribute__((noinline)) void nhwc_item(pb_kernarg_t pbp, dirs_kerna
       const unsigned long long rb = sm.mbits[16 * nn + lr] >> lq;
       lo[nn] = (unsigned)rb; hi[nn] = (unsigned)(rb >> 32);
     }
-    gemm_cp<MT, NTM>(G, KS,
-                     [&](int m, int ks) { return a_at(T0, m, ks); },
-                     [&](int ks) { return sm.part1[wave * 64 + 4 * ks + lq]; },
-                     [&](int nn, int ks) {
-                       const unsigned w = ks < 8 ? lo[nn] : hi[nn];
-                       return (float)((w >> ((4 * ks) & 31)) & 1u);
-                     });
-    Ge = edge_column_bits(T0, sm.mbits[P - 1] & ((1ull << P) - 1), sm.part1 + wave * 64);
+    const unsigned long long rbe = (sm.mbits[P - 1] & ((1ull << P) - 1)) >> lq;      // row 48, shifted the same way
+    const unsigned loe = (unsigned)rbe, hie = (unsigned)(rbe >> 32);
+    gemm_cp_e(G, Ge,
+              [&](int m, int ks) { return a_at(T0, m, ks); },
+              [&](int ks) { return sm.rkw[wave * 64 + 4 * ks + lq]; },
+              [&](int nn, int ks) {
+                const unsigned w = ks < 8 ? lo[nn] : hi[nn];
+                return (float)((w >> ((4 * ks) & 31)) & 1u);
+              },
+              [&](int ks) { return (float)(((ks < 8 ? loe : hie) >> ((4 * ks) & 31)) & 1u); });
   }
   STAMPN(9);
   float tc[NTM];     // <Y_hat[:, i], G[:, i]> of this lane's columns (Y raw in registers: ry applied after the reduction)
@@ -601,9 +649,10 @@ __device__ __attribute__((noinline)) void nhwc_item(pb_kernarg_t pbp, dirs_kerna
         for (int r = 0; r < 4; ++r) s = __builtin_fmaf(Y[m][nn][r], G[m][nn][r], s);
       v[nn] = s;
     }
-    // a wave overwrites only its own slice (its 1 / ||k|| copy, no longer needed); barrier: every wave is done reading k
-    float ve = elive ? Ye * Ge : 0.f;
-    col_reduce_edge<NTM>(v, ve, sm.part1);
+    // (a scratch of its own: slower waves may still be reading the norm partials in part0 / part1); barrier: every wave
+    // is done reading k
+    float ve = elive ? __builtin_fmaf(Ye[0], Ge[0], Ye[1] * Ge[1]) : 0.f;
+    col_reduce_edge<NTM>(v, ve, sm.part2, cx.wave, cx.lane);
     tce = ve * rye;
 #pragma unroll
     for (int nn = 0; nn < NTM; ++nn) tc[nn] = v[nn] * ry[nn];
@@ -625,14 +674,17 @@ __device__ __attribute__((noinline)) void nhwc_item(pb_kernarg_t pbp, dirs_kerna
   STAMPN(10);
   if (!want_grad) {
     // forward only: v (T1) and k (T0) are dead behind the barrier of the loss reduction; the next x goes to T1
-    if (gx_next) tile_dma(gx_next, T1);
+    if (gx_next) tile_dma(cx, gx_next, T1);
     return;
   }
 
   // ---- dY -> T0 (accumulator layout: one 16-B chunk per tile and lane) ----
   {
     const float gs = pb.grad_scale * -2.f / (float)N / den;
-    if (elive) T0[tix(P - 1, erow)] = __builtin_fmaf(-Ye, rye * rye * (gs * tce), Ge * (gs * rye));
+    if (elive) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m) T0[tix(P - 1, erow(m))] = __builtin_fmaf(-Ye[m], rye * rye * (gs * tce), Ge[m] * (gs * rye));
+    }
 #pragma unroll
     for (int nn = 0; nn < NTM; ++nn) {
       // (gs G - Y_hat ti) ry with Y_hat = Y ry, ti = gs <Y_hat, G>:  G (gs ry) - Y (ry ry ti)
@@ -650,7 +702,7 @@ __device__ __attribute__((noinline)) void nhwc_item(pb_kernarg_t pbp, dirs_kerna
   // ---- dA = dY^T v_hat ; dS = dA o D, in place of D ----
   {
     f32x4 acc0 = zero4, acc1 = zero4;
-    gemm_pp_pair128(acc0, acc1, T0, T1, wave, wave + NWAVES);
+    gemm_pp_pair128(cx, acc0, acc1, T0, T1, wave, wave + NWAVES);
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int tt = wave + NWAVES * t;
@@ -674,13 +726,15 @@ __device__ __attribute__((noinline)) void nhwc_item(pb_kernarg_t pbp, dirs_kerna
     for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int nn = 0; nn < NTM; ++nn) Tv[m][nn] = zero4;
-    gemm_cp<MT, NTM>(Tv, KS,
-                     [&](int m, int ks) { return a_at(T0, m, ks); },
-                     [&](int) { return 1.f; },
-                     [&](int nn, int ks) { return sm.AA[(4 * ks + lq) * LS + 16 * nn + lr]; });
-    float Te = edge_column(T0, lane < P ? sm.AA[lane * LS + (P - 1)] : 0.f, sm.part1 + wave * 64);
-    const float ve = T1[tix(P - 1, erow)];
-    float ves = elive ? ve * Te * sm.rv[P - 1] : 0.f;     // column 48: partial of the projection dot product
+    float Te[MT], ve[MT];
+    gemm_cp_e(Tv, Te,
+              [&](int m, int ks) { return a_at(T0, m, ks); },
+              [&](int) { return 1.f; },
+              [&](int nn, int ks) { return sm.AA[(4 * ks + lq) * LS + 16 * nn + lr]; },
+              [&](int ks) { return sm.AA[(4 * ks + lq) * LS + (P - 1)]; });
+#pragma unroll
+    for (int m = 0; m < MT; ++m) ve[m] = T1[tix(P - 1, erow(m))];
+    float ves = elive ? __builtin_fmaf(ve[0], Te[0], ve[1] * Te[1]) * sm.rv[P - 1] : 0.f;     // column 48: partial of the projection dot product
     float4 vh[MT][NTM];
     float v[NTM];
 #pragma unroll
@@ -695,9 +749,9 @@ __device__ __attribute__((noinline)) void nhwc_item(pb_kernarg_t pbp, dirs_kerna
       v[nn] = s * sm.rv[16 * nn + lr];
     }
     STAMPN(13);
-    col_reduce_edge<NTM>(v, ves, sm.part0);          // barrier inside: every wave is done reading dY from T0
+    col_reduce_edge<NTM>(v, ves, sm.part0, cx.wave, cx.lane);          // barrier inside: every wave is done reading dY from T0
     STAMPN(14);
-    tile_dma(gx, T0);                                // x again (second read: L2 / MALL hit), under the dv epilogue
+    tile_dma(cx, gx, T0);                                // x again (second read: L2 / MALL hit), under the dv epilogue
 #pragma unroll
     for (int nn = 0; nn < NTM; ++nn) {
       const float rvj = sm.rv[16 * nn + lr], cj = rvj * rvj * v[nn];      // (T - v_hat s) rv = T rv - v (rv rv s)
@@ -709,21 +763,17 @@ __device__ __attribute__((noinline)) void nhwc_item(pb_kernarg_t pbp, dirs_kerna
     }
     if (elive) {
       const float rve = sm.rv[P - 1];
-      T1[tix(P - 1, erow)] = __builtin_fmaf(-ve, rve * rve * ves, Te * rve);
+#pragma unroll
+      for (int m = 0; m < MT; ++m) T1[tix(P - 1, erow(m))] = __builtin_fmaf(-ve[m], rve * rve * ves, Te[m] * rve);
     }
   }
   __syncthreads();                                   // dv complete in T1; dS complete in DM
   STAMPN(15);
-  tile_store(dd.dv + (size_t)n * tile, T1);
-  // dSs = dS + dS^T in place (rows / columns >= P are zero because D is zero there): thread e owns the pair (i, j), i < j
-  for (int e = tid; e < LR * LR; e += NTHREADS) {
-    const int i = e / LR, j = e - i * LR;
-    if (i < j) {
-      const float s2 = sm.DM[i * LS + j] + sm.DM[j * LS + i];
-      sm.DM[i * LS + j] = s2; sm.DM[j * LS + i] = s2;
-    } else if (i == j) {
-      sm.DM[i * LS + i] = 2.f * sm.DM[i * LS + i];
-    }
+  tile_store(cx, dd.dv + (size_t)n * tile, T1);
+  // dSs = dS + dS^T -> AA, which is dead since the dV contraction (rows / columns >= P are zero because D is zero there)
+  for (int e = tid; e < LR * 64; e += NTHREADS) {
+    const int i = e >> 6, j = e & 63;
+    sm.AA[i * LS + j] = (j < LR) ? sm.DM[i * LS + j] + sm.DM[j * LS + i] : 0.f;
   }
   STAMPN(16);
   wait_vm<0>();                                      // this wave's rows of x have landed (and its dv stores have left)
@@ -737,13 +787,15 @@ __device__ __attribute__((noinline)) void nhwc_item(pb_kernarg_t pbp, dirs_kerna
     for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int nn = 0; nn < NTM; ++nn) Tx[m][nn] = zero4;
-    gemm_cp<MT, NTM>(Tx, KS,
-                     [&](int m, int ks) { return a_at(T0, m, ks); },
-                     [&](int ks) { return sm.rx[4 * ks + lq]; },
-                     [&](int nn, int ks) { return sm.DM[(4 * ks + lq) * LS + 16 * nn + lr]; });
-    float Te = edge_column(T0, lane < P ? sm.rx[lane] * sm.DM[lane * LS + (P - 1)] : 0.f, sm.part0 + wave * 64);
-    const float xe = T0[tix(P - 1, erow)];
-    float xes = elive ? xe * Te * sm.rx[P - 1] : 0.f;
+    float Te[MT], xe[MT];
+    gemm_cp_e(Tx, Te,
+              [&](int m, int ks) { return a_at(T0, m, ks); },
+              [&](int ks) { return sm.rx[4 * ks + lq]; },
+              [&](int nn, int ks) { return sm.AA[(4 * ks + lq) * LS + 16 * nn + lr]; },
+              [&](int ks) { return sm.AA[(4 * ks + lq) * LS + (P - 1)]; });
+#pragma unroll
+    for (int m = 0; m < MT; ++m) xe[m] = T0[tix(P - 1, erow(m))];
+    float xes = elive ? __builtin_fmaf(xe[0], Te[0], xe[1] * Te[1]) * sm.rx[P - 1] : 0.f;
     float4 xh[MT][NTM];
     float v[NTM];
 #pragma unroll
@@ -758,9 +810,30 @@ __device__ __attribute__((noinline)) void nhwc_item(pb_kernarg_t pbp, dirs_kerna
       v[nn] = s * sm.rx[16 * nn + lr];
     }
     STAMPN(18);
-    col_reduce_edge<NTM>(v, xes, sm.part1);          // barrier inside: every wave is done reading x from T0
+    col_reduce_edge<NTM>(v, xes, sm.part1, cx.wave, cx.lane);          // barrier inside: every wave is done reading x from T0
     STAMPN(19);
-    if (gx_next) tile_dma(gx_next, T1);              // the next item's x travels under this item's tail
+    if (gx_next) tile_dma(cx, gx_next, T1);              // the next item's x travels under this item's tail
+#if !NHWC_CALL_BODY
+    if (wave == 0 && gx_next) {                          // ... and so do the lines its sample points will tap (struct Warm)
+      const int n2 = bn % N;
+      const pixpro_dir d2 = kernarg_load<pixpro_dir>(&Dp->d[bn / N]);
+      if (d2.lo_own == nullptr && d2.flow != nullptr) {
+        int Ho, Wo;
+        frame_size_uniform(pb, d2, Ho, Wo);
+        const float wo1 = (float)(Wo - 1), ho1 = (float)(Ho - 1);
+        const Crop cq = crop_of_uniform(d2.coord_q + (size_t)n2 * 10, pb.H, pb.W);
+        const Crop ck = crop_of_uniform(d2.coord_k + (size_t)n2 * 10, pb.H, pb.W);
+        const int pt = min(lane, P - 1), row = pt / pb.W, col = pt % pb.W;
+        const FlowGeom fg2 = flow_geom(pb.Hf, pb.Wf, Ho, Wo);
+        const PointTaps t2 = displace_fetch(d2.flow + (size_t)n2 * 2 * pb.Hf * pb.Wf,
+                                            d2.mask ? d2.mask + (size_t)n2 * pb.Hf * pb.Wf : nullptr, fg2,
+                                            centre_x(cq, col, wo1) + 0.f * ck.bw, centre_y(cq, row, ho1));
+        warm.v[0] = t2.ax; warm.v[1] = t2.ay; warm.v[2] = t2.bx; warm.v[3] = t2.by;
+        warm.v[4] = t2.cx; warm.v[5] = t2.cy; warm.v[6] = t2.dx; warm.v[7] = t2.dy;
+        warm.m = t2.m;
+      }
+    }
+#endif
 #pragma unroll
     for (int nn = 0; nn < NTM; ++nn) {
       const float rxj = sm.rx[16 * nn + lr], cj = rxj * rxj * v[nn];
@@ -772,12 +845,13 @@ __device__ __attribute__((noinline)) void nhwc_item(pb_kernarg_t pbp, dirs_kerna
     }
     if (elive) {
       const float rxe = sm.rx[P - 1];
-      T0[tix(P - 1, erow)] = __builtin_fmaf(-xe, rxe * rxe * xes, Te * rxe);
+#pragma unroll
+      for (int m = 0; m < MT; ++m) T0[tix(P - 1, erow(m))] = __builtin_fmaf(-xe[m], rxe * rxe * xes, Te[m] * rxe);
     }
   }
   __syncthreads();
   STAMPN(20);
-  tile_store(dd.dx + (size_t)n * tile, T0);
+  tile_store(cx, dd.dx + (size_t)n * tile, T0);
   STAMPN(21);
 }
 
@@ -793,14 +867,27 @@ ppm_nhwc_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* __
   const pb_kernarg_t pbp = (pb_kernarg_t)ka;
   const dirs_kernarg_t Dp = (dirs_kernarg_t)(ka + sizeof(pixpro_problem));
   const int tid = threadIdx.x;
+#ifdef PIXPRO_STAMPS
+  if (blockIdx.x == gridDim.x - 1 && tid == 0) g_stamps[30] = __builtin_amdgcn_s_memtime();
+#endif
   for (int e = tid; e < (TROWS - P) * TS; e += NTHREADS) { sm.T[P * TS + e] = 0.f; sm.T[TILE + P * TS + e] = 0.f; }
   int b = blockIdx.x;
   if (b >= nitems) return;
-  tile_dma(D.d[b / pb.N].x + (size_t)(b % pb.N) * (C * P), sm.T);
+  tile_dma(lane_ctx(), D.d[b / pb.N].x + (size_t)(b % pb.N) * (C * P), sm.T);
   int flip = 0;
+#if !NHWC_CALL_BODY
+  Warm warm;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) warm.v[i] = 0.f;
+  warm.m = 0u;
+#endif
 #pragma clang loop unroll(disable)
   for (; b < nitems; b += gridDim.x) {
+#if NHWC_CALL_BODY
     nhwc_item(pbp, Dp, loss_n, pos_num, pos_mean, b, nitems, flip);
+#else
+    nhwc_item(pb, Dp, loss_n, pos_num, pos_mean, b, nitems, flip, warm);
+#endif
     flip ^= 1;
   }
 }

@@ -36,9 +36,9 @@ __device__ __forceinline__ void col_reduce_reg(float (&v)[NT], float* part) {
 // for it (0 in lanes that hold none) and comes back as its total in every lane.  Slot 48 of a wave's slice is free
 // because NT = 3 column tiles use slots 0..47.
 template <int NT>
-__device__ __forceinline__ void col_reduce_edge(float (&v)[NT], float& ve, float* part) {
+__device__ __forceinline__ void col_reduce_edge(float (&v)[NT], float& ve, float* part, int wave, int lane) {
   static_assert(NT == 3, "slot 48 is the first free one");
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, lr = lane & 15;
+  const int lr = lane & 15;
   const float se = wave_sum(ve);
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
@@ -60,6 +60,11 @@ __device__ __forceinline__ void col_reduce_edge(float (&v)[NT], float& ve, float
 #pragma unroll
   for (int w = 0; w < NWAVES; ++w) te += part[w * 64 + 48];
   ve = te;
+}
+
+template <int NT>
+__device__ __forceinline__ void col_reduce_edge(float (&v)[NT], float& ve, float* part) {
+  col_reduce_edge<NT>(v, ve, part, __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), threadIdx.x & 63);
 }
 
 // C x P contraction: acc[m][n] += sum_k Aop(m, k) * Bop(n, k), k in steps of 4.  Software-pipelined by hand: the

@@ -55,6 +55,11 @@ inline BnCaps bn_caps() {
   }();
   return caps;
 }
+// PIXPRO_BN_FOLD=0: partial sums folded by k_stats_finalize / k_bwd_finalize launches instead of the last work-group
+inline bool bn_fold_in_kernel() {
+  static const bool on = [] { const char* e = getenv("PIXPRO_BN_FOLD"); return !(e && e[0] == '0'); }();
+  return on;
+}
 inline BnTile bn_tile(int64_t M, int C4, int cap) {
   BnTile t;
   t.TX = 1;
@@ -95,30 +100,6 @@ __device__ __forceinline__ void block_rows_sum(float4& a, float4& b, int TX, int
   }
 }
 
-// partial[by][0][C] = sum (x - K), partial[by][1][C] = sum (x - K)^2,  K = x[0][c]; the last work-group of a chunk:
-// packed[0..C) = mean, packed[C..2C) = biased variance, packed[2C] = M     (what one rank contributes)
-__global__ void __launch_bounds__(BN_TPB)
-k_stats(const float* __restrict__ x, int* __restrict__ tickets, float* __restrict__ partial, float* __restrict__ packed,
-        int64_t M, int C4, int TX, int TY) {
-  __shared__ float4 sh[2 * BN_TPB];
-  float4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
-  const float4 K = ld4(x, blockIdx.x * TX + (threadIdx.x & (TX - 1)));
-#define BODY(row) { const float4 v = ld4(x, (row) * C4 + c4);                                                  \
-    const float dx_ = v.x - K.x, dy_ = v.y - K.y, dz_ = v.z - K.z, dw_ = v.w - K.w;                            \
-    s.x += dx_; s.y += dy_; s.z += dz_; s.w += dw_;                                                           \
-    q.x = __builtin_fmaf(dx_, dx_, q.x); q.y = __builtin_fmaf(dy_, dy_, q.y);                                  \
-    q.z = __builtin_fmaf(dz_, dz_, q.z); q.w = __builtin_fmaf(dw_, dw_, q.w); }
-  BN_ROWS(BODY)
-#undef BODY
-  block_rows_sum(s, q, TX, TY, sh);
-  if (ty == 0) {
-    const int64_t C = (int64_t)C4 * 4;
-    float* p = partial + (int64_t)blockIdx.y * 2 * C;
-    st4(p, c4, s);
-    st4(p + C, c4, q);
-  }
-}
-
 // ---- last-work-group fold -------------------------------------------------------------------------------------------
 // The workspace starts with BN_HDR int32 tickets (one per channel chunk = blockIdx.x), zero before the launch; every
 // work-group publishes its partial rows (release), draws a ticket, and the one that draws gridDim.y - 1 sums the gridDim.y
@@ -136,16 +117,25 @@ __device__ __forceinline__ bool last_block_fold(int* __restrict__ tickets, const
   const int tx = threadIdx.x & (TX - 1), ty = threadIdx.x / TX, c4 = blockIdx.x * TX + tx;
   const int nblk = gridDim.y;
   const int64_t C = (int64_t)C4 * 4;
+  if (!tickets) return false;          // the caller folds with a launch of its own
   if (nblk > 1) {
-    __threadfence();                   // this work-group's partial rows are visible device-wide ...
+    // ONE agent-scope release per work-group, by one lane, once every wave's partial stores have reached L2 - and one
+    // acquire in the work-group that turns out to be last.  (A __threadfence() in every thread, the first version of
+    // this, made bn_stats twice and bn_backward_reduce three times slower: 86 / 289 us per call instead of 45 / 94.)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-      const int t = __hip_atomic_fetch_add(tickets + blockIdx.x, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const int t = __hip_atomic_fetch_add(tickets + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       is_last = t == nblk - 1;
+      if (t == nblk - 1) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
     }
     __syncthreads();
     if (!is_last) return false;
-    __threadfence();                   // ... and everybody else's to this one
   }
   s = D4{0.0, 0.0, 0.0, 0.0}; q = s;
   for (int b = ty; b < nblk; b += TY) {
@@ -159,6 +149,93 @@ __device__ __forceinline__ bool last_block_fold(int* __restrict__ tickets, const
   if (ty != 0) return false;
   for (int k = 1; k < TY; ++k) { d4_add(s, red[0][k * TX + tx]); d4_add(q, red[1][k * TX + tx]); }
   return true;
+}
+
+// partial[by][0][C] = sum (x - K), partial[by][1][C] = sum (x - K)^2,  K = x[0][c]; the last work-group of a chunk:
+// packed[0..C) = mean, packed[C..2C) = biased variance, packed[2C] = M     (what one rank contributes)
+__global__ void __launch_bounds__(BN_TPB)
+k_stats(const float* __restrict__ x, int* __restrict__ tickets, float* __restrict__ partial, float* __restrict__ packed,
+        int64_t M, int C4, int TX, int TY) {
+  __shared__ float4 sh[2 * BN_TPB];
+  float4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
+  const float4 K = ld4(x, blockIdx.x * TX + (threadIdx.x & (TX - 1)));
+#define BODY(row) { const float4 v = ld4(x, (row) * C4 + c4);                                                  \
+    const float dx_ = v.x - K.x, dy_ = v.y - K.y, dz_ = v.z - K.z, dw_ = v.w - K.w;                            \
+    s.x += dx_; s.y += dy_; s.z += dz_; s.w += dw_;                                                           \
+    q.x = __builtin_fmaf(dx_, dx_, q.x); q.y = __builtin_fmaf(dy_, dy_, q.y);                                  \
+    q.z = __builtin_fmaf(dz_, dz_, q.z); q.w = __builtin_fmaf(dw_, dw_, q.w); }
+  BN_ROWS(BODY)
+#undef BODY
+  block_rows_sum(s, q, TX, TY, sh);
+  const int64_t C = (int64_t)C4 * 4;
+  if (ty == 0) {
+    float* p = partial + (int64_t)blockIdx.y * 2 * C;
+    st4(p, c4, s);
+    st4(p + C, c4, q);
+  }
+  D4 ds, dq;
+  if (!last_block_fold(tickets, partial, C4, TX, TY, ds, dq)) return;
+  const double n = (double)M;
+  const double sv[4] = {ds.x, ds.y, ds.z, ds.w}, qv[4] = {dq.x, dq.y, dq.z, dq.w};
+  const float kv[4] = {K.x, K.y, K.z, K.w};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {        // scalar stores: a view's record [2C + 1] need not start on a 16-B boundary
+    const double ms = sv[k] / n;
+    packed[4 * c4 + k] = (float)((double)kv[k] + ms);
+    packed[C + 4 * c4 + k] = (float)fmax(qv[k] / n - ms * ms, 0.0);
+  }
+  if (c4 == 0) packed[2 * C] = (float)M;
+}
+
+// ---- the same fold as launches of their own (PIXPRO_BN_FOLD=0: the round-1..3 form, kept for A/B and as the fallback) ----
+// Column sums of the [nblk][2][C] partials: 8 channels x 32 row groups per block, double accumulation (the partials are
+// long sums themselves), fixed order.  Returns the two totals of channel c in the g == 0 lanes.
+constexpr int FIN_CH = 8, FIN_G = BN_TPB / FIN_CH;
+__device__ __forceinline__ bool finalize_sums(const float* __restrict__ partial, int nblk, int C, int& c, double& s,
+                                              double& q) {
+  __shared__ double red[2][FIN_G][FIN_CH];
+  const int lc = threadIdx.x % FIN_CH, g = threadIdx.x / FIN_CH;
+  c = blockIdx.x * FIN_CH + lc;
+  s = 0.0; q = 0.0;
+  if (c < C)
+    for (int b = g; b < nblk; b += FIN_G) {
+      s += (double)partial[(int64_t)b * 2 * C + c];
+      q += (double)partial[(int64_t)b * 2 * C + C + c];
+    }
+  red[0][g][lc] = s;
+  red[1][g][lc] = q;
+  __syncthreads();
+  if (g != 0 || c >= C) return false;
+  for (int k = 1; k < FIN_G; ++k) { s += red[0][k][lc]; q += red[1][k][lc]; }
+  return true;
+}
+
+// packed[0..C) = mean, packed[C..2C) = biased variance, packed[2C] = M     (what one rank contributes)
+__global__ void __launch_bounds__(BN_TPB)
+k_stats_finalize(const float* __restrict__ x, const float* __restrict__ partial, int nblk, int64_t M, int C,
+                 float* __restrict__ packed) {
+  int c;
+  double s, q;
+  if (!finalize_sums(partial, nblk, C, c, s, q)) return;
+  const double n = (double)M;
+  const double ms = s / n;
+  packed[c] = (float)((double)x[c] + ms);
+  packed[C + c] = (float)fmax(q / n - ms * ms, 0.0);
+  if (c == 0) packed[2 * C] = (float)M;
+}
+
+// sums[0..C) = sum dz, sums[C..2C) = sum dz (x - mean)   (this rank); grad_weight = sums[C+c] * invstd, grad_bias
+__global__ void __launch_bounds__(BN_TPB)
+k_bwd_finalize(const float* __restrict__ partial, int nblk, int C, const float* __restrict__ invstd,
+               float* __restrict__ sums, float* __restrict__ grad_weight, float* __restrict__ grad_bias) {
+  int c;
+  double sd, qd;
+  if (!finalize_sums(partial, nblk, C, c, sd, qd)) return;
+  const float s = (float)sd, q = (float)qd;
+  sums[c] = s;
+  sums[C + c] = q;
+  if (grad_weight) grad_weight[c] = q * invstd[c];
+  if (grad_bias) grad_bias[c] = s;
 }
 
 // Count-weighted merge of the ranks' statistics for one channel (batch_norm_gather_stats_with_counts), in double.
@@ -336,9 +413,14 @@ size_t bn_workspace_floats(int64_t M, int C) {
 
 int run_bn_stats(const float* x, int64_t M, int C, float* ws, float* packed, hipStream_t st) {
   const BnTile t = bn_tile(M, C / 4, bn_caps().stats);
-  hipLaunchKernelGGL(k_stats, dim3(t.gx, t.gy), dim3(BN_TPB), 0, st, x, reinterpret_cast<int*>(ws), ws + BN_HDR, packed, M,
-                     C / 4, t.TX, t.TY);
+  const bool fold = bn_fold_in_kernel();
+  hipLaunchKernelGGL(k_stats, dim3(t.gx, t.gy), dim3(BN_TPB), 0, st, x, fold ? reinterpret_cast<int*>(ws) : nullptr, ws + BN_HDR,
+                     packed, M, C / 4, t.TX, t.TY);
   CHECKED("k_stats");
+  if (!fold) {
+    hipLaunchKernelGGL(k_stats_finalize, dim3((C + FIN_CH - 1) / FIN_CH), dim3(BN_TPB), 0, st, x, ws + BN_HDR, t.gy, M, C, packed);
+    CHECKED("k_stats_finalize");
+  }
   return PIXPRO_OK;
 }
 
@@ -366,8 +448,10 @@ int run_bn_bwd_reduce(const float* dy, const float* x, const float* y, const flo
                       float* grad_bias, hipStream_t st) {
   const BnTile t = bn_tile(M, C / 4, bn_caps().bwd_reduce);
   const dim3 g(t.gx, t.gy), b(BN_TPB);
+  const bool fold = bn_fold_in_kernel();
 #define REDUCE(MD) hipLaunchKernelGGL((k_bwd_reduce<MD>), g, b, 0, st, dy, x, y, scale_shift, mean, invstd,                \
-                                     reinterpret_cast<int*>(ws), ws + BN_HDR, sums, grad_weight, grad_bias, M, C / 4, t.TX, t.TY)
+                                     fold ? reinterpret_cast<int*>(ws) : nullptr, ws + BN_HDR, sums, grad_weight, grad_bias, M, \
+                                     C / 4, t.TX, t.TY)
   switch (mask_mode(relu, scale_shift)) {
     case 0: REDUCE(0); break;
     case 1: REDUCE(1); break;
@@ -375,6 +459,11 @@ int run_bn_bwd_reduce(const float* dy, const float* x, const float* y, const flo
   }
 #undef REDUCE
   CHECKED("k_bwd_reduce");
+  if (!fold) {
+    hipLaunchKernelGGL(k_bwd_finalize, dim3((C + FIN_CH - 1) / FIN_CH), dim3(BN_TPB), 0, st, ws + BN_HDR, t.gy, C, invstd, sums,
+                       grad_weight, grad_bias);
+    CHECKED("k_bwd_finalize");
+  }
   return PIXPRO_OK;
 }
 

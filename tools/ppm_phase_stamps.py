@@ -11,7 +11,7 @@ PKG = os.path.join(ROOT, "pixpro-with-opticalflow_amd")
 sys.path.insert(0, PKG)
 torch = None
 
-NAMES_NHWC = ["start", "wait x (top barrier)", "v dma, pts, S gemm", "v wait, barrier, k dma", "rx, maskbits", "rv norms", "S epilogue",
+NAMES_NHWC = ["start", "wait x (top barrier)", "v dma, pts, S gemm", "barrier, k dma", "rx, maskbits", "S epilogue", "v wait, rv norms",
               "Y gemm + edge", "ny, rk", "G gemm + edge", "loss reduce", "dY, barrier", "dA gemm + epi", "dV gemm + edge",
               "dV reduce", "x dma, dv epi, barrier", "dv store, symm", "x wait, barrier", "dX gemm + edge", "dX reduce",
               "next-x dma, dx epi, barrier", "dx store"]
@@ -76,11 +76,13 @@ def main():
     buf = (ctypes.c_ulonglong * 64)()
     assert _native.load().pixpro_debug_stamps(buf) == 0
     if nhwc:
-        st = list(buf)[32:54]
-        tot = st[-1] - st[0]
-        print(f"NHWC kernel, last item of the last work-group (N={N}): total ticks {tot}")
-        for i in range(1, len(st)):
-            print(f"{NAMES_NHWC[i]:>28s} {st[i] - st[i - 1]:8d} {100.0 * (st[i] - st[i - 1]) / tot:5.1f}%")
+        first, last, t_start = list(buf)[0:22], list(buf)[32:54], list(buf)[30]
+        print(f"NHWC kernel, last work-group (N={N}): kernel entry -> first item {first[0] - t_start} ticks, first item "
+              f"{first[-1] - first[0]}, last item {last[-1] - last[0]}, entry -> end of last item {last[-1] - t_start}")
+        print(f"{'phase':>28s} {'first':>8s} {'last':>8s}")
+        for i in range(1, 22):
+            print(f"{NAMES_NHWC[i]:>28s} {first[i] - first[i - 1]:8d} {last[i] - last[i - 1]:8d} "
+                  f"{100.0 * (last[i] - last[i - 1]) / (last[-1] - last[0]):5.1f}%")
         return
     st = list(buf)[:16]
     tot = st[15] - st[0]
