@@ -51,6 +51,32 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// Cross-lane sums on the vector ALU (no ds_bpermute round trips through the LDS pipe, which is what __shfl_xor compiles
+// to): gfx950's row swaps for the sum over the four 16-lane rows, DPP for the sum inside a row.
+//   rows_sum(v): lanes l, l + 16, l + 32, l + 48 all receive (v[l] + v[l+16]) + (v[l+32] + v[l+48])  (l < 16)
+//   wave_sum_valu(v): every lane receives the sum over the wave (row sums by quad / half-row / row mirrors, then rows_sum)
+// (Inline assembly on purpose: __builtin_amdgcn_permlane16/32_swap handed two copies of one value comes back from hipcc 7.2
+// with both results in ONE register - `v_permlane16_swap v7, v5 ; v_add_f32 v5, v7, v7` - i.e. 2 v instead of the row sums;
+// tools/ubench/lane_sums.hip checks these helpers against the shuffles on the device.  s_nop 1 = the two wait states a VALU
+// write of a swap operand needs before the swap reads it.)
+__device__ __forceinline__ float rows_sum(float v) {
+  float a = v, b = v;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));   // rows 1, 3 of a <-> rows 0, 2 of b
+  a = a + b;
+  b = a;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));   // lanes 32..63 of a <-> lanes 0..31 of b
+  return a + b;
+}
+#define PIXPRO_DPP_ADD(v, ctrl) \
+  ((v) + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xf, 0xf, false)))
+__device__ __forceinline__ float wave_sum_valu(float v) {
+  v = PIXPRO_DPP_ADD(v, 0xB1);      // quad_perm [1,0,3,2]
+  v = PIXPRO_DPP_ADD(v, 0x4E);      // quad_perm [2,3,0,1]
+  v = PIXPRO_DPP_ADD(v, 0x141);     // row_half_mirror
+  v = PIXPRO_DPP_ADD(v, 0x140);     // row_mirror
+  return rows_sum(v);
+}
+
 // ---------------------------------------------------------------------------------------
 // Crop geometry, contrast/models/PixPro.py:140-157,168-175.  c = coord row [10].
 // ---------------------------------------------------------------------------------------

@@ -78,6 +78,7 @@ struct Smem {
   float* part1;
   float* part2;
   float* rkw;    // [NWAVES][64] every wave's own copy of 1 / ||k_j||
+  float* part3;  // [NWAVES][64] scratch of the dV reduction (part0..rkw hold the dA partials meanwhile)
   float* qx;     // [64] each
   float* qy;
   float* kx;
@@ -86,7 +87,7 @@ struct Smem {
   unsigned long long* mbits;  // [64]
   int* valid;    // [64]
 };
-constexpr size_t SMEM_FLOATS = 2 * TILE + 2 * LR * LS + 3 * 64 + 4 * NWAVES * 64 + 4 * 64 + 32 + 2 * 64 + 64;
+constexpr size_t SMEM_FLOATS = 2 * TILE + 2 * LR * LS + 3 * 64 + 5 * NWAVES * 64 + 4 * 64 + 32 + 2 * 64 + 64;
 
 __device__ __forceinline__ Smem carve(float* base) {
   Smem s;
@@ -95,7 +96,7 @@ __device__ __forceinline__ Smem carve(float* base) {
   s.AA = p; p += LR * LS;
   s.DM = p; p += LR * LS;
   s.rx = p; p += 64; s.rv = p; p += 64; s.nx2 = p; p += 64;
-  s.part0 = p; p += NWAVES * 64; s.part1 = p; p += NWAVES * 64; s.part2 = p; p += NWAVES * 64; s.rkw = p; p += NWAVES * 64;
+  s.part0 = p; p += NWAVES * 64; s.part1 = p; p += NWAVES * 64; s.part2 = p; p += NWAVES * 64; s.rkw = p; p += NWAVES * 64; s.part3 = p; p += NWAVES * 64;
   s.qx = p; p += 64; s.qy = p; p += 64; s.kx = p; p += 64; s.ky = p; p += 64;
   s.misc = p; p += 32;
   s.mbits = (unsigned long long*)p; p += 2 * 64;
@@ -110,6 +111,17 @@ __device__ __forceinline__ void tile_dma(const Ctx& cx, const float* __restrict_
 #pragma unroll
   for (int i = 0; i < 7; ++i) {
     const int p = wave + NWAVES * i;
+    if (p < P) dma16(g + p * C + 4 * (lane ^ swz(p)), T + p * TS);
+  }
+}
+// The same issued by waves 1..6 only (the S phase: waves 0 and 7 run latency chains on the vector ALU there and every copy
+// a wave issues stalls it for ~200 cycles while the texture path takes the 1-KB row)
+__device__ __forceinline__ void tile_dma_mid(const Ctx& cx, const float* __restrict__ g, float* T) {
+  const int wave = cx.wave, lane = cx.lane;
+  if (wave < 1 || wave > 6) return;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    const int p = (wave - 1) + 6 * i;
     if (p < P) dma16(g + p * C + 4 * (lane ^ swz(p)), T + p * TS);
   }
 }
@@ -130,11 +142,14 @@ __device__ __forceinline__ float col_sumsq_part(const Ctx& cx, const float* T) {
   const int p = min(lane, P - 1), s = swz(p);
   const float* row = T + p * TS;
   float a0 = 0.f, a1 = 0.f;
+  float4 t[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) t[q] = *reinterpret_cast<const float4*>(row + 4 * ((8 * wave + q) ^ s));
+  __builtin_amdgcn_sched_barrier(0);          // all eight requested before the first is consumed
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
-    const float4 t = *reinterpret_cast<const float4*>(row + 4 * ((8 * wave + q) ^ s));
-    a0 = __builtin_fmaf(t.x, t.x, a0); a1 = __builtin_fmaf(t.y, t.y, a1);
-    a0 = __builtin_fmaf(t.z, t.z, a0); a1 = __builtin_fmaf(t.w, t.w, a1);
+    a0 = __builtin_fmaf(t[q].x, t[q].x, a0); a1 = __builtin_fmaf(t[q].y, t[q].y, a1);
+    a0 = __builtin_fmaf(t[q].z, t[q].z, a0); a1 = __builtin_fmaf(t[q].w, t[q].w, a1);
   }
   return a0 + a1;
 }
@@ -182,6 +197,33 @@ __device__ __forceinline__ f32x4 gemm_pp_tile128(const Ctx& cx, const float* __r
   for (int r = 0; r < 4; ++r) acc[r] = acc0[r] + acc1[r];
   return acc;
 }
+// ng groups of 16 channels (4 MFMA steps each) of one tile, starting at group g0: a K slice of gemm_pp_tile128
+__device__ __forceinline__ f32x4 gemm_pp_tile128_slice(const Ctx& cx, const float* __restrict__ L, const float* __restrict__ R,
+                                                    int ti, int tj, int g0) {
+  const int lr = cx.lr, lq = cx.lq;
+  const int pa = 16 * ti + lr, pb = 16 * tj + lr;
+  const float* la = L + pa * TS + 4 * (lq ^ swz(pa)) + 16 * g0;
+  const float* rb = R + pb * TS + 4 * (lq ^ swz(pb)) + 16 * g0;
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  float4 a[4], b[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    a[u] = *reinterpret_cast<const float4*>(la + 16 * u);
+    b[u] = *reinterpret_cast<const float4*>(rb + 16 * u);
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    acc0 = mfma16(a[u].x, b[u].x, acc0);
+    acc1 = mfma16(a[u].y, b[u].y, acc1);
+    acc0 = mfma16(a[u].z, b[u].z, acc0);
+    acc1 = mfma16(a[u].w, b[u].w, acc1);
+  }
+  f32x4 acc;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc[r] = acc0[r] + acc1[r];
+  return acc;
+}
+
 // Two tiles at once (dA on the padded 4 x 4 grid: tiles `wave` and `wave + 8`), one accumulator each
 __device__ __forceinline__ void gemm_pp_pair128(const Ctx& cx, f32x4& acc0, f32x4& acc1, const float* __restrict__ L,
                                                 const float* __restrict__ R, int t0, int t1) {
@@ -222,6 +264,31 @@ __device__ __forceinline__ void gemm_pp_pair128(const Ctx& cx, f32x4& acc0, f32x
   }
 }
 
+// col_reduce_edge of ppm_fused_shared.h with the cross-lane sums on the vector ALU (rows_sum / wave_sum_valu, common.h): on
+// return every lane holds in v[n] the sum over all C rows of its column 16 n + lr and in ve the total of column 48.
+__device__ __forceinline__ void col_reduce_e(float (&v)[NTM], float& ve, float* part, int wave, int lane) {
+  const int lr = lane & 15;
+  const float se = wave_sum_valu(ve);
+#pragma unroll
+  for (int n = 0; n < NTM; ++n) {
+    const float sn = rows_sum(v[n]);
+    if (lane < 16) part[wave * 64 + 16 * n + lane] = sn;
+  }
+  if (lane == 0) part[wave * 64 + 48] = se;
+  __syncthreads();
+#pragma unroll
+  for (int n = 0; n < NTM; ++n) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < NWAVES; ++w) t += part[w * 64 + 16 * n + lr];
+    v[n] = t;
+  }
+  float te = 0.f;
+#pragma unroll
+  for (int w = 0; w < NWAVES; ++w) te += part[w * 64 + 48];
+  ve = te;
+}
+
 // C x P contraction on three column tiles with column 48 riding along on the vector ALU: the A values a lane loads for the
 // MFMAs - element (row 16 (wave + 8 m) + lr, k = 4 ks + lq), already scaled - are exactly what the 49th column needs, so it
 // costs one more B value per k-step (fe(ks) = B[k][48]) and MT FMAs, hidden between the MFMAs, instead of a pass of its own
@@ -259,10 +326,7 @@ __device__ __forceinline__ void gemm_cp_e(f32x4 (&acc)[MT][NTM], float (&e)[MT],
     sc = scn; be = ben;
   }
 #pragma unroll
-  for (int m = 0; m < MT; ++m) {
-    e[m] += __shfl_xor(e[m], 16, 64);
-    e[m] += __shfl_xor(e[m], 32, 64);
-  }
+  for (int m = 0; m < MT; ++m) e[m] = rows_sum(e[m]);
 }
 
 typedef const pixpro_problem __attribute__((address_space(4))) * pb_kernarg_t;
@@ -350,7 +414,10 @@ __device__ __forceinline__ void nhwc_item(const pixpro_problem& pb, dirs_kernarg
 #endif
   __syncthreads();
   STAMPN(1);
-  tile_dma(cx, gv, T1);                   // v streams in under the S contraction (one tile request at a time)
+  // v streams in under the S contraction (one tile request at a time).  A wave is stalled for ~2 k cycles while it issues
+  // its rows (all CUs ask the memory system for a tile at the same moment), so the two MFMA waves of a SIMD take turns:
+  // waves 4..6 request before their tile product, waves 1..3 after it - one of each pair always has MFMAs to issue.
+  if (wave >= 4) tile_dma_mid(cx, gv, T1);
 
   // lazy flow mode with a chain (nframe > 2): the nine composed-flow pixels each point needs (common.h) are spread over
   // the work-group, two dependent stages through LDS (the AA matrix is not live yet)
@@ -381,28 +448,29 @@ __device__ __forceinline__ void nhwc_item(const pixpro_problem& pb, dirs_kernarg
     }
     __syncthreads();
   }
-  // ---- wave 0: bin centres, flow taps (ONE round trip, consumed after its share of the S phase), threshold ----
-  float ptx = 0.f, pty = 0.f, pkx = 0.f, pky = 0.f;
+  // ---- wave 0: the q-side sample points - bin centres, flow taps (ONE round trip) - the longest latency chain of the phase;
+  // the k-side centres and the threshold of the positive-pair test ride on wave 7 behind its row-48 dot products
+  float ptx = 0.f, pty = 0.f;
   bool ptv = true, dense = false;
   PointTaps taps;      // written and read by wave 0 in dense mode only (not zero-initialised on purpose, see ppm_fused.hip)
   FlowGeom fgd;
   if (wave == 0) {
+    // this chain and wave 7's work below share their SIMDs with one MFMA wave each and are the longer halves: they go first
+    __builtin_amdgcn_s_setprio(3);
     int Ho, Wo;
     frame_size_uniform(pb, dd, Ho, Wo);
     const float wo1 = (float)(Wo - 1), ho1 = (float)(Ho - 1);
     const Crop cq = crop_of_uniform(dd.coord_q + (size_t)n * 10, pb.H, pb.W);
-    const Crop ck = crop_of_uniform(dd.coord_k + (size_t)n * 10, pb.H, pb.W);
     const int pt = min(lane, P - 1), row = pt / pb.W, col = pt % pb.W;
     ptx = centre_x(cq, col, wo1); pty = centre_y(cq, row, ho1);
-    pkx = centre_x(ck, col, wo1); pky = centre_y(ck, row, ho1);
+    STAMPN(22);
     dense = dd.lo_own == nullptr && dd.flow != nullptr;
     if (dense) {
       fgd = flow_geom(pb.Hf, pb.Wf, Ho, Wo);
       taps = displace_fetch(dd.flow + (size_t)n * 2 * pb.Hf * pb.Wf,
                             dd.mask ? dd.mask + (size_t)n * pb.Hf * pb.Wf : nullptr, fgd, ptx, pty);
     }
-    const float T = dist_threshold(fmaxf(bin_diag(cq, wo1, ho1), bin_diag(ck, wo1, ho1)), pb.pos_ratio, lane);
-    if (lane == 0) sm.misc[2] = T;
+    STAMPN(23);
     if (dd.lo_own) {            // lazy flow mode: evaluate flow + validity at this point from the low-res maps
       const FlowGeom fg = flow_geom(8 * pb.lo_h, 8 * pb.lo_w, Ho, Wo);
       const LazySrc ls = lazy_src(pb, dd, n);
@@ -411,38 +479,72 @@ __device__ __forceinline__ void nhwc_item(const pixpro_problem& pb, dirs_kernarg
       else displace_point_lazy(ls, fg, ptx, pty, ox, oy, ptv);
       ptx = ox; pty = oy;
     }
+    STAMPN(24);
   }
 
   // ---- S_raw = x^T x ; rx from its diagonal ; S, A, D ----
   // S is symmetric and 49 = 48 + 1: the six upper tiles of the 3 x 3 tile grid go to the matrix cores, one per wave
-  // 1..6, and are mirrored by the epilogue; wave 7 takes row 48 (49 dot products over C) on the vector ALU; wave 0 has the
-  // sample points (a latency chain: crop records -> flow taps).
+  // 1..6, and are mirrored by the epilogue; row 48 (49 dot products over C) runs on the vector ALU, an eighth of C per wave;
+  // wave 0 has the q-side sample points (a latency chain: crop records -> flow taps), wave 7 the k side and the threshold.
   const int sw_ = wave - 1;                                                            // tile of waves 1..6
   const int sti = (sw_ >= 3) + (sw_ >= 5), stj = sw_ - (sw_ >= 3 ? 2 : 0) - (sw_ >= 5 ? 1 : 0);
   const bool stile = wave >= 1 && wave <= 6;
   f32x4 accS = zero4;
   if (stile) {
     accS = gemm_pp_tile128(cx, T0, T0, sti, stj);
+    if (wave <= 3) tile_dma_mid(cx, gv, T1);
+#ifdef PIXPRO_STAMPS
+    if (stamp_on >= 0 && threadIdx.x == 64) g_stamps[stamp_on + 27] = __builtin_amdgcn_s_memtime();
+#endif
     if (sti == stj) {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         if (4 * lq + r == lr) sm.nx2[16 * sti + lr] = accS[r];
     }
   } else if (wave == 7) {
+#ifdef PIXPRO_STAMPS
+    if (stamp_on >= 0 && threadIdx.x == 448) g_stamps[stamp_on + 28] = __builtin_amdgcn_s_memtime();
+#endif
+    __builtin_amdgcn_s_setprio(3);
+    // the k-side bin centres and the threshold of the positive-pair test (they need only the two crop records)
+    int Ho, Wo;
+    frame_size_uniform(pb, dd, Ho, Wo);
+    const float wo1 = (float)(Wo - 1), ho1 = (float)(Ho - 1);
+    const Crop cq = crop_of_uniform(dd.coord_q + (size_t)n * 10, pb.H, pb.W);
+    const Crop ck = crop_of_uniform(dd.coord_k + (size_t)n * 10, pb.H, pb.W);
+    const int pt = min(lane, P - 1), row = pt / pb.W, col = pt % pb.W;
+    const bool live = lane < P;
+    sm.kx[lane] = live ? centre_x(ck, col, wo1) : 0.f;
+    sm.ky[lane] = live ? centre_y(ck, row, ho1) : 0.f;
+    const float T = dist_threshold(fmaxf(bin_diag(cq, wo1, ho1), bin_diag(ck, wo1, ho1)), pb.pos_ratio, lane);
+    if (lane == 0) sm.misc[2] = T;
+    __builtin_amdgcn_s_setprio(0);
+#ifdef PIXPRO_STAMPS
+    if (stamp_on >= 0 && threadIdx.x == 448) g_stamps[stamp_on + 29] = __builtin_amdgcn_s_memtime();
+#endif
+  }
+  // Row 48 of the raw Gram matrix (49 dot products over C) on the vector ALU, split over the channels: every wave takes its
+  // 32 (8 chunks requested at once; one wave alone needed 5-6 k cycles for the 64), the partials meet in `part2`
+  {
     const int jj = min(lane, P - 1), sj = swz(jj);
     const float* xj = T0 + jj * TS;
     const float* xe = T0 + (P - 1) * TS;            // swz(48) == 0
-    float e0 = 0.f, e1 = 0.f, e2 = 0.f, e3 = 0.f;
-#pragma unroll 8
-    for (int q = 0; q < 64; ++q) {
-      const float4 u = *reinterpret_cast<const float4*>(xe + 4 * q);
-      const float4 w = *reinterpret_cast<const float4*>(xj + 4 * (q ^ sj));
-      e0 = __builtin_fmaf(u.x, w.x, e0); e1 = __builtin_fmaf(u.y, w.y, e1);
-      e2 = __builtin_fmaf(u.z, w.z, e2); e3 = __builtin_fmaf(u.w, w.w, e3);
+    float4 u[8], w[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      u[q] = *reinterpret_cast<const float4*>(xe + 4 * (8 * wave + q));
+      w[q] = *reinterpret_cast<const float4*>(xj + 4 * ((8 * wave + q) ^ sj));
     }
-    sm.part1[lane] = (e0 + e1) + (e2 + e3);             // part1 is next used by the Y-norm reduction
+    __builtin_amdgcn_sched_barrier(0);
+    float e0 = 0.f, e1 = 0.f, e2 = 0.f, e3 = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      e0 = __builtin_fmaf(u[q].x, w[q].x, e0); e1 = __builtin_fmaf(u[q].y, w[q].y, e1);
+      e2 = __builtin_fmaf(u[q].z, w[q].z, e2); e3 = __builtin_fmaf(u[q].w, w[q].w, e3);
+    }
+    sm.part2[wave * 64 + lane] = (e0 + e1) + (e2 + e3);
   }
-  if (wave == 0) {                 // the sample points: taps requested above, the threshold search ran under their latency
+  if (wave == 0) {                 // the sample points: the taps requested above have had the S phase to arrive
     if (dense) {
       float ox, oy;
       displace_finish(taps, fgd, ptx, pty, ox, oy, ptv);
@@ -450,16 +552,25 @@ __device__ __forceinline__ void nhwc_item(const pixpro_problem& pb, dirs_kernarg
     }
     const bool live = lane < P;
     sm.qx[lane] = live ? ptx : 0.f; sm.qy[lane] = live ? pty : 0.f;
-    sm.kx[lane] = live ? pkx : 0.f; sm.ky[lane] = live ? pky : 0.f;
     sm.valid[lane] = (live && ptv) ? 1 : 0;
+    __builtin_amdgcn_s_setprio(0);
   }
   STAMPN(2);
   __syncthreads();                 // every wave is done with x in T0; nx2 / row 48 / the sample points are published
-  tile_dma(cx, gk, T0);            // k streams in under the mask / S epilogue / norm / Y phases
+  // k streams in under the mask / S epilogue / norm phases; the same turn-taking: waves 4..7 request now, waves 0..3 after
+  // the mask rows and the S epilogue
+  if (wave >= 4) tile_dma(cx, gk, T0);
   STAMPN(3);
   // 1 / ||x_j|| from the diagonal of the raw Gram matrix: every lane works out the few it needs (the S epilogue below
   // runs before the next barrier), lanes 0..63 also publish the vector for the dX contraction
-  auto rxof = [&](int j) { return 1.f / fmaxf(sqrtf(j < 48 ? sm.nx2[j] : sm.part1[48]), 1e-12f); };
+  auto row48 = [&](int j) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < NWAVES; ++w) t += sm.part2[w * 64 + j];
+    return t;
+  };
+  const float n48 = row48(P - 1);
+  auto rxof = [&](int j) { return 1.f / fmaxf(sqrtf(j < 48 ? sm.nx2[j] : n48), 1e-12f); };
   if (tid < 64) sm.rx[tid] = rxof(min(tid, P - 1));
   // ---- positive-pair bit mask: row i of M = ballot over j (PixPro.py:217-223); row i's point comes out of lane i ----
   {
@@ -499,7 +610,7 @@ __device__ __forceinline__ void nhwc_item(const pixpro_problem& pb, dirs_kernarg
     const int t2 = (wave == 7 ? 0 : 64) + lane;      // 0..127
     if (t2 < P) {
       float a, d;
-      pow_map(sm.part1[t2] * rxof(P - 1) * rxof(t2), pb.p, pb.clamp, a, d);
+      pow_map(row48(t2) * rxof(P - 1) * rxof(t2), pb.p, pb.clamp, a, d);
       sm.AA[(P - 1) * LS + t2] = a; sm.DM[(P - 1) * LS + t2] = d;
       sm.AA[t2 * LS + (P - 1)] = a; sm.DM[t2 * LS + (P - 1)] = d;
     }
@@ -512,6 +623,7 @@ __device__ __forceinline__ void nhwc_item(const pixpro_problem& pb, dirs_kernarg
       sm.AA[i * LS + jz] = 0.f; sm.DM[i * LS + jz] = 0.f;
     }
   }
+  if (wave < 4) tile_dma(cx, gk, T0);
   STAMPN(5);
   // ---- rv = 1 / ||v_j||.  v was requested at the top of the item; its copies are older than the (6 or 7) copies of k this
   // wave has just issued and copies complete in order, so "at most six outstanding" means v has landed.
@@ -555,7 +667,7 @@ __device__ __forceinline__ void nhwc_item(const pixpro_problem& pb, dirs_kernarg
   float ry[NTM];     // 1 / ||Y[:, i]|| of this lane's columns
   float rye = 0.f;   // ... and of column 48
   {
-    const float qe = wave_sum(elive ? __builtin_fmaf(Ye[0], Ye[0], Ye[1] * Ye[1]) : 0.f);
+    const float qe = wave_sum_valu(elive ? __builtin_fmaf(Ye[0], Ye[0], Ye[1] * Ye[1]) : 0.f);
     if (lane == 0) sm.part1[wave * 64 + 48] = qe;
 #pragma unroll
     for (int nn = 0; nn < NTM; ++nn) {
@@ -564,8 +676,7 @@ __device__ __forceinline__ void nhwc_item(const pixpro_problem& pb, dirs_kernarg
       for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int r = 0; r < 4; ++r) q = __builtin_fmaf(Y[m][nn][r], Y[m][nn][r], q);
-      q += __shfl_xor(q, 16, 64);
-      q += __shfl_xor(q, 32, 64);
+      q = rows_sum(q);
       if (lane < 16) sm.part1[wave * 64 + 16 * nn + lane] = q;
     }
     __syncthreads();
@@ -652,7 +763,7 @@ __device__ __forceinline__ void nhwc_item(const pixpro_problem& pb, dirs_kernarg
     // (a scratch of its own: slower waves may still be reading the norm partials in part0 / part1); barrier: every wave
     // is done reading k
     float ve = elive ? __builtin_fmaf(Ye[0], Ge[0], Ye[1] * Ge[1]) : 0.f;
-    col_reduce_edge<NTM>(v, ve, sm.part2, cx.wave, cx.lane);
+    col_reduce_e(v, ve, sm.part2, cx.wave, cx.lane);
     tce = ve * rye;
 #pragma unroll
     for (int nn = 0; nn < NTM; ++nn) tc[nn] = v[nn] * ry[nn];
@@ -664,7 +775,7 @@ __device__ __forceinline__ void nhwc_item(const pixpro_problem& pb, dirs_kernarg
 #pragma unroll
     for (int nn = 0; nn < NTM; ++nn) t += lane < 16 ? tc[nn] : 0.f;
     if (lane == 0) t += tce;
-    t = wave_sum(t);
+    t = wave_sum_valu(t);
     if (lane == 0) {
       loss_n[b] = t / den;
       pos_num[b] = cnt;
@@ -700,21 +811,54 @@ __device__ __forceinline__ void nhwc_item(const pixpro_problem& pb, dirs_kernarg
   STAMPN(11);
 
   // ---- dA = dY^T v_hat ; dS = dA o D, in place of D ----
+  // 49 = 48 + 1 once more: the 3 x 3 tiles over i, j < 48 go to the matrix cores - tiles 0..7 one per wave, tile (2, 2) as four
+  // K slices on waves 4..7 (a SIMD holds waves w and w + 4: 64 + 80 MFMAs each, against 256 on the padded 4 x 4 grid) - and
+  // row 48 / column 48 are dot products on the vector ALU, every wave over its own 32 channels.  The slices and the edge
+  // partials meet in LDS (the four reduction scratch arrays, idle here) and are folded behind the dV contraction's barrier.
+  float* const PK = sm.part0;                    // [4][256] tile (2,2) slices | [8][64] row-48 partials | [8][64] column-48 partials
   {
-    f32x4 acc0 = zero4, acc1 = zero4;
-    gemm_pp_pair128(cx, acc0, acc1, T0, T1, wave, wave + NWAVES);
+    const int mi = wave / 3, nj = wave - 3 * mi;
+    const f32x4 acc = gemm_pp_tile128(cx, T0, T1, mi, nj);
+    const int j = 16 * nj + lr;
+    const float rvj = sm.rv[j];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int tt = wave + NWAVES * t;
-      const f32x4& acc = t ? acc1 : acc0;
-      const int mi = tt >> 2, nj = tt & 3, j = 16 * nj + lr;
-      const float rvj = sm.rv[j];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i = 16 * mi + 4 * lq + r;
-        if (i < LR) sm.DM[i * LS + j] = acc[r] * rvj * sm.DM[i * LS + j];      // D is zero beyond P: so is dS
-      }
+    for (int r = 0; r < 4; ++r) {
+      const int i = 16 * mi + 4 * lq + r;
+      sm.DM[i * LS + j] = acc[r] * rvj * sm.DM[i * LS + j];
     }
+    if (wave >= 4) {
+      const f32x4 part = gemm_pp_tile128_slice(cx, T0, T1, 2, 2, 4 * (wave - 4));
+#pragma unroll
+      for (int r = 0; r < 4; ++r) PK[(wave - 4) * 256 + (4 * lq + r) * 16 + lr] = part[r];
+    }
+    // edges: lane j < 49: dA[48][j] over this wave's channels; lane i < 48: dA[i][48]
+    const int pj = min(lane, P - 1), sj = swz(pj);
+    const float* yr = T0 + pj * TS;              // dY row of pixel pj (column edge), v row of pixel pj (row edge)
+    const float* vr = T1 + pj * TS;
+    const float* y48 = T0 + (P - 1) * TS;        // swz(48) == 0
+    const float* v48 = T1 + (P - 1) * TS;
+    float er0 = 0.f, er1 = 0.f, ec0 = 0.f, ec1 = 0.f;
+#pragma unroll
+    for (int q0 = 0; q0 < 8; q0 += 4) {           // four chunks of each of the four rows requested at a time
+      float4 a48[4], b48[4], bj[4], ai[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int ql = 8 * wave + q0 + q;
+        a48[q] = *reinterpret_cast<const float4*>(y48 + 4 * ql); b48[q] = *reinterpret_cast<const float4*>(v48 + 4 * ql);
+        bj[q] = *reinterpret_cast<const float4*>(vr + 4 * (ql ^ sj)); ai[q] = *reinterpret_cast<const float4*>(yr + 4 * (ql ^ sj));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        er0 = __builtin_fmaf(a48[q].x, bj[q].x, er0); er1 = __builtin_fmaf(a48[q].y, bj[q].y, er1);
+        er0 = __builtin_fmaf(a48[q].z, bj[q].z, er0); er1 = __builtin_fmaf(a48[q].w, bj[q].w, er1);
+        ec0 = __builtin_fmaf(ai[q].x, b48[q].x, ec0); ec1 = __builtin_fmaf(ai[q].y, b48[q].y, ec1);
+        ec0 = __builtin_fmaf(ai[q].z, b48[q].z, ec0); ec1 = __builtin_fmaf(ai[q].w, b48[q].w, ec1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    PK[1024 + wave * 64 + lane] = er0 + er1;
+    PK[1536 + wave * 64 + lane] = ec0 + ec1;
   }
   STAMPN(12);
   // (no barrier: the dV contraction reads dY and A, not DM; dS is first read by the symmetrisation behind two barriers)
@@ -749,9 +893,31 @@ __device__ __forceinline__ void nhwc_item(const pixpro_problem& pb, dirs_kernarg
       v[nn] = s * sm.rv[16 * nn + lr];
     }
     STAMPN(13);
-    col_reduce_edge<NTM>(v, ves, sm.part0, cx.wave, cx.lane);          // barrier inside: every wave is done reading dY from T0
+    col_reduce_e(v, ves, sm.part3, cx.wave, cx.lane);          // barrier inside: every wave is done reading dY from T0
     STAMPN(14);
-    tile_dma(cx, gx, T0);                                // x again (second read: L2 / MALL hit), under the dv epilogue
+    if (wave >= 4) tile_dma(cx, gx, T0);                 // x again (second read: L2 / MALL hit), under the dv epilogue ...
+    // the dA partials (complete behind that barrier), fixed order: tile (2,2) from its four K slices, row 48, column 48
+    if (tid < 256) {
+      const int i = 32 + (tid >> 4), j = 32 + (tid & 15);
+      const float t = (PK[tid] + PK[256 + tid]) + (PK[512 + tid] + PK[768 + tid]);
+      sm.DM[i * LS + j] = t * sm.rv[j] * sm.DM[i * LS + j];
+    } else if (tid < 256 + 64) {
+      const int j = tid - 256;
+      if (j < P) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < NWAVES; ++w) t += PK[1024 + w * 64 + j];
+        sm.DM[(P - 1) * LS + j] = t * sm.rv[j] * sm.DM[(P - 1) * LS + j];
+      }
+    } else if (tid < 256 + 128) {
+      const int i = tid - 320;
+      if (i < P - 1) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < NWAVES; ++w) t += PK[1536 + w * 64 + i];
+        sm.DM[i * LS + (P - 1)] = t * sm.rv[P - 1] * sm.DM[i * LS + (P - 1)];
+      }
+    }
 #pragma unroll
     for (int nn = 0; nn < NTM; ++nn) {
       const float rvj = sm.rv[16 * nn + lr], cj = rvj * rvj * v[nn];      // (T - v_hat s) rv = T rv - v (rv rv s)
@@ -767,6 +933,7 @@ __device__ __forceinline__ void nhwc_item(const pixpro_problem& pb, dirs_kernarg
       for (int m = 0; m < MT; ++m) T1[tix(P - 1, erow(m))] = __builtin_fmaf(-ve[m], rve * rve * ves, Te[m] * rve);
     }
   }
+  if (wave < 4) tile_dma(cx, gx, T0);                // ... the other half of its rows (turn-taking, see the S phase)
   __syncthreads();                                   // dv complete in T1; dS complete in DM
   STAMPN(15);
   tile_store(cx, dd.dv + (size_t)n * tile, T1);
@@ -781,6 +948,9 @@ __device__ __forceinline__ void nhwc_item(const pixpro_problem& pb, dirs_kernarg
   STAMPN(17);
 
   // ---- dX_hat = x_hat dSs ; dx = (dX_hat - x_hat s) / n_x ----
+  // T1 is free behind the barrier above (dv has left): the next item's x travels from here on, requested by waves 0..3 in
+  // front of the contraction ...
+  if (wave < 4 && gx_next) tile_dma(cx, gx_next, T1);
   {
     f32x4 Tx[MT][NTM];
 #pragma unroll
@@ -793,6 +963,7 @@ __device__ __forceinline__ void nhwc_item(const pixpro_problem& pb, dirs_kernarg
               [&](int ks) { return sm.rx[4 * ks + lq]; },
               [&](int nn, int ks) { return sm.AA[(4 * ks + lq) * LS + 16 * nn + lr]; },
               [&](int ks) { return sm.AA[(4 * ks + lq) * LS + (P - 1)]; });
+    if (wave >= 4 && gx_next) tile_dma(cx, gx_next, T1);     // ... by waves 4..7 behind it
 #pragma unroll
     for (int m = 0; m < MT; ++m) xe[m] = T0[tix(P - 1, erow(m))];
     float xes = elive ? __builtin_fmaf(xe[0], Te[0], xe[1] * Te[1]) * sm.rx[P - 1] : 0.f;
@@ -810,9 +981,8 @@ __device__ __forceinline__ void nhwc_item(const pixpro_problem& pb, dirs_kernarg
       v[nn] = s * sm.rx[16 * nn + lr];
     }
     STAMPN(18);
-    col_reduce_edge<NTM>(v, xes, sm.part1, cx.wave, cx.lane);          // barrier inside: every wave is done reading x from T0
+    col_reduce_e(v, xes, sm.part1, cx.wave, cx.lane);          // barrier inside: every wave is done reading x from T0
     STAMPN(19);
-    if (gx_next) tile_dma(cx, gx_next, T1);              // the next item's x travels under this item's tail
 #if !NHWC_CALL_BODY
     if (wave == 0 && gx_next) {                          // ... and so do the lines its sample points will tap (struct Warm)
       const int n2 = bn % N;

@@ -7,18 +7,18 @@
 // (profiles/r01_syncbn_microbench.txt).  These kernels keep the same split (local statistics | exchange | apply),
 // so the collectives stay where torch has them, and stream x as [M = N*H*W rows][C] with 16 B per lane:
 //
-//   forward   k_stats (1 read of x; its last work-group per channel chunk folds the partials)
+//   forward   k_stats (1 read of x) -> k_stats_finalize (or, PIXPRO_BN_FOLD=1, the last work-group per channel chunk)
 //             -> [all_gather of 2C+1 floats] -> k_apply (merges the ranks' records in its prologue)
 //             k_apply: y = relu?( (x-mean)*invstd*w + b (+ residual) )                      (read x [,res], write y)
-//   backward  k_bwd_reduce: dz = dy * (y > 0)?; sum dz, sum dz*(x-mean)                      (read dy, x [,y]; same fold)
+//   backward  k_bwd_reduce: dz = dy * (y > 0)?; sum dz, sum dz*(x-mean) -> k_bwd_finalize      (read dy, x [,y]; same option)
 //             -> [all_reduce of 2C floats] -> k_bwd_apply: dx [, dres = dz]                   (read dy, x [,y])
 //
 // Statistics are accumulated as shifted sums (pivot = the channel's first element), so the variance does not suffer
 // the E[x^2]-E[x]^2 cancellation; partial sums are combined in a fixed order (deterministic; the only atomic is the ticket
 // that tells a work-group it is the last of its channel chunk to finish - which one that is does not enter the result).
-// Round 4: the partials used to be folded by two one-block launches per layer and direction (k_stats_finalize,
-// k_bwd_finalize: 324 launches, 5.7 ms per ResNet-50 step, serial between the streaming kernels); now the work-group that
-// draws the last ticket of its chunk does it before it exits.
+// Round 4: folding the partials in the producing kernel (the work-group that draws the last ticket of its channel chunk
+// does it before it exits) was built to remove the 324 small finalize launches of a step - and measured slower than they
+// are (bn_fold_in_kernel below); it stays selectable, the launches stay the default and read eight rows per thread at once.
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -55,10 +55,13 @@ inline BnCaps bn_caps() {
   }();
   return caps;
 }
-// PIXPRO_BN_FOLD=0: partial sums folded by k_stats_finalize / k_bwd_finalize launches instead of the last work-group
+// Measured on MI355X, ResNet-50 step at N = 256 (profiles/r04_bn_fold_ab.txt): in-kernel fold 67.3 ms of BatchNorm per step
+// (bn_stats 13.1, bn_backward_reduce 18.8 ms) against 57.7 ms with the two small launches (10.5 / 11.8 ms), 1134 against
+// 1173 images/s: the one agent-scope release every work-group needs before it may draw its ticket costs the streaming kernels
+// more than the launches cost.  So the launches stay the default; PIXPRO_BN_FOLD=1 selects the in-kernel fold.
 inline bool bn_fold_in_kernel() {
-  static const bool on = [] { const char* e = getenv("PIXPRO_BN_FOLD"); return !(e && e[0] == '0'); }();
-  return on;
+  const char* e = getenv("PIXPRO_BN_FOLD");      // read per call: tests switch it at run time
+  return e && e[0] == '1';
 }
 inline BnTile bn_tile(int64_t M, int C4, int cap) {
   BnTile t;
@@ -187,7 +190,7 @@ k_stats(const float* __restrict__ x, int* __restrict__ tickets, float* __restric
   if (c4 == 0) packed[2 * C] = (float)M;
 }
 
-// ---- the same fold as launches of their own (PIXPRO_BN_FOLD=0: the round-1..3 form, kept for A/B and as the fallback) ----
+// ---- the same fold as launches of their own: the default (see bn_fold_in_kernel) ----
 // Column sums of the [nblk][2][C] partials: 8 channels x 32 row groups per block, double accumulation (the partials are
 // long sums themselves), fixed order.  Returns the two totals of channel c in the g == 0 lanes.
 constexpr int FIN_CH = 8, FIN_G = BN_TPB / FIN_CH;
@@ -197,11 +200,26 @@ __device__ __forceinline__ bool finalize_sums(const float* __restrict__ partial,
   const int lc = threadIdx.x % FIN_CH, g = threadIdx.x / FIN_CH;
   c = blockIdx.x * FIN_CH + lc;
   s = 0.0; q = 0.0;
-  if (c < C)
-    for (int b = g; b < nblk; b += FIN_G) {
+  if (c < C) {
+    // eight rows in flight per thread (round 4: one dependent round trip per row made this one-block-per-8-channels
+    // launch cost 21 us per layer; the summation order - rows g, g + 32, ... in turn - is unchanged)
+    constexpr int U = 8;
+    int b = g;
+    for (; b + (U - 1) * FIN_G < nblk; b += U * FIN_G) {
+      float sv[U], qv[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        sv[u] = partial[(int64_t)(b + u * FIN_G) * 2 * C + c];
+        qv[u] = partial[(int64_t)(b + u * FIN_G) * 2 * C + C + c];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) { s += (double)sv[u]; q += (double)qv[u]; }
+    }
+    for (; b < nblk; b += FIN_G) {
       s += (double)partial[(int64_t)b * 2 * C + c];
       q += (double)partial[(int64_t)b * 2 * C + C + c];
     }
+  }
   red[0][g][lc] = s;
   red[1][g][lc] = q;
   __syncthreads();

@@ -397,12 +397,14 @@ def test_flush_counters_makes_buffer_walks_current(dev):
     assert int(net.state_dict()["1.num_batches_tracked"]) == 4
 
 
-def test_last_block_fold_is_repeatable_and_stream_safe(dev):
-    """Round 4: the partial sums of bn_stats / bn_backward_reduce are folded by the work-group that draws the last ticket of
-    its channel chunk (no finalize launches).  Which work-group that is varies from launch to launch; the result must
-    not: 40 forward+backward passes over the same tensors agree bit for bit, also when two streams run different layers at
-    the same time (each stream owns its ticket workspace), and the tickets are left at zero."""
+@pytest.mark.parametrize("fold", ["0", "1"])
+def test_partial_sum_fold_is_repeatable_and_stream_safe(dev, fold, monkeypatch):
+    """The partial sums of bn_stats / bn_backward_reduce are folded either by a small launch (default) or, PIXPRO_BN_FOLD=1,
+    by the work-group that draws the last ticket of its channel chunk.  Which work-group that is varies from launch to
+    launch; the result must not: 40 forward+backward passes over the same tensors agree bit for bit in both modes, also when
+    two streams run different layers at the same time (each stream owns its workspace), and the tickets are left at zero."""
     from contrast import _native as nv
+    monkeypatch.setenv("PIXPRO_BN_FOLD", fold)
     from contrast.sync_bn import FusedSyncBatchNorm
     g = torch.Generator().manual_seed(11)
     shapes = [(64, 64, 56, 56), (32, 256, 28, 28), (16, 2048, 7, 7), (3, 12, 5, 7)]

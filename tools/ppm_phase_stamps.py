@@ -83,6 +83,11 @@ def main():
         for i in range(1, 22):
             print(f"{NAMES_NHWC[i]:>28s} {first[i] - first[i - 1]:8d} {last[i] - last[i - 1]:8d} "
                   f"{100.0 * (last[i] - last[i - 1]) / (last[-1] - last[0]):5.1f}%")
+        for name, base in (("first", 0), ("last", 32)):
+            b_ = list(buf)[base:base + 32]
+            print(f"{name} item, S phase from the top barrier (stamp 1): wave 0 crop records + centres {b_[22] - b_[1]}, taps requested "
+                  f"{b_[23] - b_[1]}, threshold {b_[24] - b_[1]}, points done {b_[2] - b_[1]}; wave 1 tile done {b_[27] - b_[1]}; "
+                  f"wave 7 row 48 from {b_[28] - b_[1]} to {b_[29] - b_[1]}")
         return
     st = list(buf)[:16]
     tot = st[15] - st[0]
