@@ -329,7 +329,6 @@ __device__ __forceinline__ void gemm_cp_e(f32x4 (&acc)[MT][NTM], float (&e)[MT],
   for (int m = 0; m < MT; ++m) e[m] = rows_sum(e[m]);
 }
 
-typedef const pixpro_problem __attribute__((address_space(4))) * pb_kernarg_t;
 typedef const Dirs __attribute__((address_space(4))) * dirs_kernarg_t;
 typedef const pixpro_dir __attribute__((address_space(4))) * dir_kernarg_t;
 // scalar loads of a struct from the kernel-argument segment (the host pass of hipcc only needs this to parse)
@@ -342,33 +341,13 @@ __device__ __forceinline__ T kernarg_load(const T __attribute__((address_space(4
 #endif
 }
 
-// One (direction, sample) item.  Deliberately NOT inlined into the persistent loop of the kernel: inlined, the compiler
-// hoists every lane-derived address of the body out of the loop (hundreds of registers live across the whole item:
-// 256 VGPRs plus spills); as a function the body is allocated like a straight-line kernel.  pb / D are read from the
-// kernel-argument segment (scalar loads), the LDS carve is recomputed from the dynamic LDS base.  `flip` selects which
-// tile buffer plays T0 for this item.
-// The flow taps of the NEXT item, requested by wave 0 while the current item finishes and never used as values: the
-// loads pull the lines into the cache hierarchy (and the crop records into the scalar cache), so that the real
-// displace_fetch at the top of the next item - a chain of two dependent round trips that nothing hides once the x tile is
-// prefetched - finds them near.  The registers stay reserved until the next item has waited for them.
-struct Warm {
-  float v[8];
-  unsigned m;
-};
-
-#ifndef NHWC_CALL_BODY
-#define NHWC_CALL_BODY 0     // 1: the item body as a non-inlined function (kept for comparison: costs ~60 callee-saved VGPR spills)
-#endif
-#if NHWC_CALL_BODY
-__device__ __attribute__((noinline)) void nhwc_item(pb_kernarg_t pbp, dirs_kernarg_t Dp, float* __restrict__ loss_n,
-                                                     float* __restrict__ pos_num, float* __restrict__ pos_mean, int b,
-                                                     int nitems, int flip) {
-  const pixpro_problem pb = kernarg_load<pixpro_problem>(pbp);
-#else
+// One (direction, sample) item, inlined into the persistent loop of the kernel.  The lane coordinates come from an opaque
+// copy of threadIdx.x (lane_ctx) so that the body's addresses are recomputed per item instead of being hoisted out of the
+// loop (256 VGPRs + spills); a non-inlined function was the first cure and cost ~60 callee-saved VGPR spills per call
+// (profiles/NOTES_r04.md).  `flip` selects which tile buffer plays T0 for this item.
 __device__ __forceinline__ void nhwc_item(const pixpro_problem& pb, dirs_kernarg_t Dp, float* __restrict__ loss_n,
                                           float* __restrict__ pos_num, float* __restrict__ pos_mean, int b, int nitems,
-                                          int flip, Warm& warm) {
-#endif
+                                          int flip) {
   extern __shared__ __attribute__((aligned(16))) float smem_raw[];
   const Smem sm = carve(smem_raw);
   const int N = pb.N;
@@ -376,17 +355,19 @@ __device__ __forceinline__ void nhwc_item(const pixpro_problem& pb, dirs_kernarg
   const int tid = cx.tid, wave = cx.wave, lane = cx.lane, lr = cx.lr, lq = cx.lq;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   constexpr int tile = C * P;
-  // A operand of the C x P products: element (channel 16 (wave + 8 m) + lr, pixel k = 4 ks + lq).  swz(k) = ks & 3 is
+  // A wave owns the 32 contiguous channels 32 wave .. 32 wave + 31 (two row tiles m) - one 128-B line of every pixel's row,
+  // which lets the gradients leave straight from the accumulator registers in full lines.
+  // A operand of the C x P products: element (channel 32 wave + 16 m + lr, pixel k = 4 ks + lq).  swz(k) = ks & 3 is
   // uniform, and bits 2..3 of the lane offset hold lr >> 2 and nothing else (TS = 256 + 16), so the swizzle is one XOR.
-  const int aoff = lq * TS + 16 * wave + 4 * (lr >> 2) + (lr & 3);
-  auto a_at = [&](const float* T, int m, int ks) { return T[(aoff ^ (4 * (ks & 3))) + 4 * ks * TS + 128 * m]; };
-  // accumulator layout: register r of tile (m, nn) is (channel 16 (wave + 8 m) + 4 lq + r, pixel 16 nn + lr): the four r are
+  const int aoff = lq * TS + 32 * wave + 4 * (lr >> 2) + (lr & 3);
+  auto a_at = [&](const float* T, int m, int ks) { return T[(aoff ^ (4 * (ks & 3))) + 4 * ks * TS + 16 * m]; };
+  // accumulator layout: register r of tile (m, nn) is (channel 32 wave + 16 m + 4 lq + r, pixel 16 nn + lr): the four r are
   // one 16-B chunk of the pixel's row
-  auto c_at = [&](int m, int nn) { return tix(16 * nn + lr, 16 * (wave + NWAVES * m) + 4 * lq); };
-  auto crow = [&](int m, int r) { return 16 * (wave + NWAVES * m) + 4 * lq + r; };
+  auto c_at = [&](int m, int nn) { return tix(16 * nn + lr, 32 * wave + 16 * m + 4 * lq); };
+  auto crow = [&](int m, int r) { return 32 * wave + 16 * m + 4 * lq + r; };
   // column 48 lives outside the MFMA tile grid: value e[m] of row erow(m), the same in the four lanes lr, lr + 16, ...; the
   // lanes below 16 speak for it in sums and stores
-  auto erow = [&](int m) { return 16 * (wave + NWAVES * m) + lr; };
+  auto erow = [&](int m) { return 32 * wave + 16 * m + lr; };
   const bool elive = lane < 16;
   float* T0 = sm.T + (flip ? TILE : 0);
   float* T1 = sm.T + (flip ? 0 : TILE);
@@ -408,10 +389,6 @@ __device__ __forceinline__ void nhwc_item(const pixpro_problem& pb, dirs_kernarg
   // x has landed in T0 (requested before the loop / during the previous item); every wave is done with the previous
   // item's tiles
   wait_vm<0>();
-#if !NHWC_CALL_BODY
-  asm volatile("" ::"v"(warm.v[0]), "v"(warm.v[1]), "v"(warm.v[2]), "v"(warm.v[3]), "v"(warm.v[4]), "v"(warm.v[5]),
-               "v"(warm.v[6]), "v"(warm.v[7]), "v"(warm.m));      // the warm-up loads of the previous item's tail have returned
-#endif
   __syncthreads();
   STAMPN(1);
   // v streams in under the S contraction (one tile request at a time).  A wave is stalled for ~2 k cycles while it issues
@@ -896,51 +873,61 @@ __device__ __forceinline__ void nhwc_item(const pixpro_problem& pb, dirs_kernarg
     col_reduce_e(v, ves, sm.part3, cx.wave, cx.lane);          // barrier inside: every wave is done reading dY from T0
     STAMPN(14);
     if (wave >= 4) tile_dma(cx, gx, T0);                 // x again (second read: L2 / MALL hit), under the dv epilogue ...
-    // the dA partials (complete behind that barrier), fixed order: tile (2,2) from its four K slices, row 48, column 48
-    if (tid < 256) {
-      const int i = 32 + (tid >> 4), j = 32 + (tid & 15);
-      const float t = (PK[tid] + PK[256 + tid]) + (PK[512 + tid] + PK[768 + tid]);
-      sm.DM[i * LS + j] = t * sm.rv[j] * sm.DM[i * LS + j];
-    } else if (tid < 256 + 64) {
-      const int j = tid - 256;
-      if (j < P) {
-        float t = 0.f;
+    // dv = (dV_hat - v_hat s) / n_v leaves straight from the accumulator registers: the two row tiles of a wave are the two
+    // 64-B halves of one line per pixel, so no staging in LDS, no barrier and no second pass over the tile
+    {
+      float* gdv = dd.dv + (size_t)n * tile;
 #pragma unroll
-        for (int w = 0; w < NWAVES; ++w) t += PK[1024 + w * 64 + j];
-        sm.DM[(P - 1) * LS + j] = t * sm.rv[j] * sm.DM[(P - 1) * LS + j];
+      for (int nn = 0; nn < NTM; ++nn) {
+        const float rvj = sm.rv[16 * nn + lr], cj = rvj * rvj * v[nn];      // (T - v_hat s) rv = T rv - v (rv rv s)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+          *reinterpret_cast<float4*>(gdv + (size_t)(16 * nn + lr) * C + crow(m, 0)) =
+              make_float4(__builtin_fmaf(-vh[m][nn].x, cj, Tv[m][nn][0] * rvj), __builtin_fmaf(-vh[m][nn].y, cj, Tv[m][nn][1] * rvj),
+                          __builtin_fmaf(-vh[m][nn].z, cj, Tv[m][nn][2] * rvj), __builtin_fmaf(-vh[m][nn].w, cj, Tv[m][nn][3] * rvj));
       }
-    } else if (tid < 256 + 128) {
-      const int i = tid - 320;
-      if (i < P - 1) {
-        float t = 0.f;
+      if (elive) {
+        const float rve = sm.rv[P - 1];
 #pragma unroll
-        for (int w = 0; w < NWAVES; ++w) t += PK[1536 + w * 64 + i];
-        sm.DM[i * LS + (P - 1)] = t * sm.rv[P - 1] * sm.DM[i * LS + (P - 1)];
+        for (int m = 0; m < MT; ++m) gdv[(size_t)(P - 1) * C + erow(m)] = __builtin_fmaf(-ve[m], rve * rve * ves, Te[m] * rve);
       }
-    }
-#pragma unroll
-    for (int nn = 0; nn < NTM; ++nn) {
-      const float rvj = sm.rv[16 * nn + lr], cj = rvj * rvj * v[nn];      // (T - v_hat s) rv = T rv - v (rv rv s)
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-        *reinterpret_cast<float4*>(T1 + c_at(m, nn)) =
-            make_float4(__builtin_fmaf(-vh[m][nn].x, cj, Tv[m][nn][0] * rvj), __builtin_fmaf(-vh[m][nn].y, cj, Tv[m][nn][1] * rvj),
-                        __builtin_fmaf(-vh[m][nn].z, cj, Tv[m][nn][2] * rvj), __builtin_fmaf(-vh[m][nn].w, cj, Tv[m][nn][3] * rvj));
-    }
-    if (elive) {
-      const float rve = sm.rv[P - 1];
-#pragma unroll
-      for (int m = 0; m < MT; ++m) T1[tix(P - 1, erow(m))] = __builtin_fmaf(-ve[m], rve * rve * ves, Te[m] * rve);
     }
   }
   if (wave < 4) tile_dma(cx, gx, T0);                // ... the other half of its rows (turn-taking, see the S phase)
-  __syncthreads();                                   // dv complete in T1; dS complete in DM
   STAMPN(15);
-  tile_store(cx, dd.dv + (size_t)n * tile, T1);
-  // dSs = dS + dS^T -> AA, which is dead since the dV contraction (rows / columns >= P are zero because D is zero there)
-  for (int e = tid; e < LR * 64; e += NTHREADS) {
-    const int i = e >> 6, j = e & 63;
-    sm.AA[i * LS + j] = (j < LR) ? sm.DM[i * LS + j] + sm.DM[j * LS + i] : 0.f;
+  // dSs = dS + dS^T -> AA (dead since the dV contraction), rows / columns 0..48 (the zero padding of the S epilogue stays).
+  // dS of the 3 x 3 tiles is in DM, tile (2,2) excepted; that tile, row 48 and column 48 are folded here from the partials of
+  // the dA phase (complete behind the barrier of the dV reduction), in a fixed order.  Three uniform passes on disjoint
+  // waves (one pass with the fold behind per-element branches took 11 k cycles):
+  if (wave < 6) {
+    // plain region: i, j < 48 without the (2,2) tile - 8 of the 9 tile positions = 2048 elements on 384 threads
+    for (int e = tid; e < 2048; e += 6 * WAVE) {
+      const int t = e >> 8, r = (e >> 4) & 15, c = e & 15;          // t: tile 0..7 in row-major order of the 3 x 3 grid
+      const int i = 16 * (t / 3) + r, j = 16 * (t - 3 * (t / 3)) + c;
+      // a partner in the (2,2) block cannot occur: (i, j) outside it means (j, i) outside it
+      sm.AA[i * LS + j] = sm.DM[i * LS + j] + sm.DM[j * LS + i];
+    }
+  } else {
+    const int t2 = tid - 6 * WAVE;                                    // 0..127
+    auto f22 = [&](int i, int j) {                                    // dS of tile (2,2): its four K slices
+      const int e2 = (i - 32) * 16 + (j - 32);
+      return ((PK[e2] + PK[256 + e2]) + (PK[512 + e2] + PK[768 + e2])) * sm.rv[j] * sm.DM[i * LS + j];
+    };
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int e = t2 + 128 * u, i = 32 + (e >> 4), j = 32 + (e & 15);
+      sm.AA[i * LS + j] = f22(i, j) + f22(j, i);
+    }
+    if (t2 < P) {                                                     // row / column 48: dSs[48][j] = dS[48][j] + dS[j][48]
+      const int j = t2;
+      float fr = 0.f, fc = 0.f;
+#pragma unroll
+      for (int w = 0; w < NWAVES; ++w) { fr += PK[1024 + w * 64 + j]; fc += PK[1536 + w * 64 + j]; }
+      const float dr = fr * sm.rv[j] * sm.DM[(P - 1) * LS + j];                          // dS[48][j]
+      const float dc = j < P - 1 ? fc * sm.rv[P - 1] * sm.DM[j * LS + (P - 1)] : dr;      // dS[j][48]  (j = 48: the same entry)
+      sm.AA[(P - 1) * LS + j] = dr + dc;
+      sm.AA[j * LS + (P - 1)] = dr + dc;
+    }
   }
   STAMPN(16);
   wait_vm<0>();                                      // this wave's rows of x have landed (and its dv stores have left)
@@ -983,45 +970,25 @@ __device__ __forceinline__ void nhwc_item(const pixpro_problem& pb, dirs_kernarg
     STAMPN(18);
     col_reduce_e(v, xes, sm.part1, cx.wave, cx.lane);          // barrier inside: every wave is done reading x from T0
     STAMPN(19);
-#if !NHWC_CALL_BODY
-    if (wave == 0 && gx_next) {                          // ... and so do the lines its sample points will tap (struct Warm)
-      const int n2 = bn % N;
-      const pixpro_dir d2 = kernarg_load<pixpro_dir>(&Dp->d[bn / N]);
-      if (d2.lo_own == nullptr && d2.flow != nullptr) {
-        int Ho, Wo;
-        frame_size_uniform(pb, d2, Ho, Wo);
-        const float wo1 = (float)(Wo - 1), ho1 = (float)(Ho - 1);
-        const Crop cq = crop_of_uniform(d2.coord_q + (size_t)n2 * 10, pb.H, pb.W);
-        const Crop ck = crop_of_uniform(d2.coord_k + (size_t)n2 * 10, pb.H, pb.W);
-        const int pt = min(lane, P - 1), row = pt / pb.W, col = pt % pb.W;
-        const FlowGeom fg2 = flow_geom(pb.Hf, pb.Wf, Ho, Wo);
-        const PointTaps t2 = displace_fetch(d2.flow + (size_t)n2 * 2 * pb.Hf * pb.Wf,
-                                            d2.mask ? d2.mask + (size_t)n2 * pb.Hf * pb.Wf : nullptr, fg2,
-                                            centre_x(cq, col, wo1) + 0.f * ck.bw, centre_y(cq, row, ho1));
-        warm.v[0] = t2.ax; warm.v[1] = t2.ay; warm.v[2] = t2.bx; warm.v[3] = t2.by;
-        warm.v[4] = t2.cx; warm.v[5] = t2.cy; warm.v[6] = t2.dx; warm.v[7] = t2.dy;
-        warm.m = t2.m;
+    {
+      float* gdx = dd.dx + (size_t)n * tile;
+#pragma unroll
+      for (int nn = 0; nn < NTM; ++nn) {
+        const float rxj = sm.rx[16 * nn + lr], cj = rxj * rxj * v[nn];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+          *reinterpret_cast<float4*>(gdx + (size_t)(16 * nn + lr) * C + crow(m, 0)) =
+              make_float4(__builtin_fmaf(-xh[m][nn].x, cj, Tx[m][nn][0] * rxj), __builtin_fmaf(-xh[m][nn].y, cj, Tx[m][nn][1] * rxj),
+                          __builtin_fmaf(-xh[m][nn].z, cj, Tx[m][nn][2] * rxj), __builtin_fmaf(-xh[m][nn].w, cj, Tx[m][nn][3] * rxj));
+      }
+      if (elive) {
+        const float rxe = sm.rx[P - 1];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) gdx[(size_t)(P - 1) * C + erow(m)] = __builtin_fmaf(-xe[m], rxe * rxe * xes, Te[m] * rxe);
       }
     }
-#endif
-#pragma unroll
-    for (int nn = 0; nn < NTM; ++nn) {
-      const float rxj = sm.rx[16 * nn + lr], cj = rxj * rxj * v[nn];
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-        *reinterpret_cast<float4*>(T0 + c_at(m, nn)) =
-            make_float4(__builtin_fmaf(-xh[m][nn].x, cj, Tx[m][nn][0] * rxj), __builtin_fmaf(-xh[m][nn].y, cj, Tx[m][nn][1] * rxj),
-                        __builtin_fmaf(-xh[m][nn].z, cj, Tx[m][nn][2] * rxj), __builtin_fmaf(-xh[m][nn].w, cj, Tx[m][nn][3] * rxj));
-    }
-    if (elive) {
-      const float rxe = sm.rx[P - 1];
-#pragma unroll
-      for (int m = 0; m < MT; ++m) T0[tix(P - 1, erow(m))] = __builtin_fmaf(-xe[m], rxe * rxe * xes, Te[m] * rxe);
-    }
   }
-  __syncthreads();
   STAMPN(20);
-  tile_store(cx, dd.dx + (size_t)n * tile, T0);
   STAMPN(21);
 }
 
@@ -1034,7 +1001,6 @@ ppm_nhwc_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* __
   const char __attribute__((address_space(4))) * ka =
       (const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
   static_assert(sizeof(pixpro_problem) % 8 == 0, "D follows pb without padding");
-  const pb_kernarg_t pbp = (pb_kernarg_t)ka;
   const dirs_kernarg_t Dp = (dirs_kernarg_t)(ka + sizeof(pixpro_problem));
   const int tid = threadIdx.x;
 #ifdef PIXPRO_STAMPS
@@ -1045,19 +1011,9 @@ ppm_nhwc_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* __
   if (b >= nitems) return;
   tile_dma(lane_ctx(), D.d[b / pb.N].x + (size_t)(b % pb.N) * (C * P), sm.T);
   int flip = 0;
-#if !NHWC_CALL_BODY
-  Warm warm;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) warm.v[i] = 0.f;
-  warm.m = 0u;
-#endif
 #pragma clang loop unroll(disable)
   for (; b < nitems; b += gridDim.x) {
-#if NHWC_CALL_BODY
-    nhwc_item(pbp, Dp, loss_n, pos_num, pos_mean, b, nitems, flip);
-#else
-    nhwc_item(pb, Dp, loss_n, pos_num, pos_mean, b, nitems, flip, warm);
-#endif
+    nhwc_item(pb, Dp, loss_n, pos_num, pos_mean, b, nitems, flip);
     flip ^= 1;
   }
 }

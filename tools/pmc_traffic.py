@@ -3,7 +3,7 @@
 (profiles/rNN_pmc_traffic.json).  Usage: tools/pmc_traffic.py OUT.json N FLOW_DIR PPM_DIR [PREVIOUS.json]
 
 Corrections (MI355X_MICROARCH.md, HBM): FETCH_SIZE reports half the bytes of 16 B/lane coalesced streaming reads -> doubled
-for ppm_fused_kernel (its reads are such streams); the flow kernels read only the 1/8-resolution maps (4-byte accesses of a
+for the single-launch PPM kernels (16 B/lane streams, through registers or LDS-DMA); the flow kernels read only the 1/8-resolution maps (4-byte accesses of a
 few KB per tile, uncalibrated width), reported uncorrected; WRITE_SIZE is exact for both.  Counters are KiB per dispatch
 (median over dispatches), collected in separate --pmc passes.  batch_norm entries are carried over from PREVIOUS (those
 kernels did not change)."""
@@ -36,7 +36,7 @@ def main():
                            "hbm_bytes_per_image": (fetch + write) * 1024 / n,
                            "valu_wave_instructions": sum(v.get("SQ_INSTS_VALU", 0.0) for v in fk.values()),
                            "salu_wave_instructions": sum(v.get("SQ_INSTS_SALU", 0.0) for v in fk.values())}
-    pk = {k: v for k, v in ppm.items() if k.startswith("ppm_fused")}
+    pk = {k: v for k, v in ppm.items() if k.startswith("ppm_nhwc")} or {k: v for k, v in ppm.items() if k.startswith("ppm_fused")}
     if pk:
         v = list(pk.values())[0]
         res["ppm_loss"] = {"fetch_kib": v.get("FETCH_SIZE", 0.0), "write_kib": v.get("WRITE_SIZE", 0.0),
