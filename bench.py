@@ -200,8 +200,8 @@ def parse():
     ap.add_argument("--no-overlap-momentum", dest="overlap_momentum", action="store_const", const="off")
     ap.add_argument("--key-bn-group", action="store_true",
                     help="EXPERIMENTAL, with several ranks: the key encoder's SyncBN collectives on a process group of their own "
-                         "(second RCCL communicator) and the key branch on its second stream (--overlap-momentum auto then "
-                         "means on).  Collectives of two communicators issued from two streams are not ordered against each "
+                         "(second RCCL communicator); combine with --overlap-momentum on to put the key branch on its second "
+                         "stream.  Collectives of two communicators issued from two streams are not ordered against each "
                          "other across ranks and may deadlock; never run over RCCL so far, off by default")
     ap.add_argument("--bn-view-batch", action="store_true",
                     help="both views of an encoder in one pass with per-view BatchNorm statistics: half the SyncBN collectives "
@@ -251,7 +251,10 @@ def model_args(a, world):
         argv.append("--fused-bn")
     if a.bn_view_batch:
         argv.append("--bn-view-batch")
-    a.overlap_momentum = a.overlap_momentum == "on" or (a.overlap_momentum == "auto" and (world == 1 or a.key_bn_group))
+    # auto = on with ONE rank only.  With several ranks the key branch on a second stream is pointless without --key-bn-group
+    # and, with it, two communicators driven from two streams may deadlock (never run over RCCL): that combination has to be
+    # asked for explicitly (--key-bn-group --overlap-momentum on), it is never switched on implicitly.
+    a.overlap_momentum = a.overlap_momentum == "on" or (a.overlap_momentum == "auto" and world == 1)
     if a.key_bn_group:
         argv.append("--key-bn-group")
     if a.overlap_momentum:

@@ -409,13 +409,31 @@ def test_nhwc_kernel_persistent_walk(dev, N):
 def test_lazy_flow_equals_dense(dev, shape, frame, lo, sigma, masked, F1):
     """--lazy-flow: flow + consistency mask evaluated inside the loss kernel at its P sample points from the 1/8-res
     maps must reproduce the dense pipeline (apply_optical_flow -> dense tensors -> loss) bit for bit."""
+    _lazy_vs_dense(dev, shape, frame, lo, sigma, masked, F1, False)
+
+
+@pytest.mark.parametrize("shape,frame,lo,sigma,masked,F1", [
+    ((6, 256, 7, 7), (96, 128), (12, 16), 0.5, True, 1), ((4, 256, 7, 7), (720, 1280), (90, 160), 0.5, True, 1),
+    ((4, 256, 7, 7), (192, 256), (12, 16), 0.5, True, 1), ((3, 256, 7, 7), (96, 128), (12, 16), 0.5, False, 1),
+    ((5, 256, 7, 7), (96, 128), (12, 16), 0.5, True, 2), ((4, 256, 7, 7), (720, 1280), (90, 160), 0.5, True, 5),
+    ((300, 256, 7, 7), (96, 128), (12, 16), 4.0, True, 5),          # more items than CUs: the persistent walk in lazy mode
+    ((2, 64, 14, 14), (96, 128), (12, 16), 1.0, True, 3),            # tiled path, channels_last in place
+])
+def test_lazy_flow_equals_dense_channels_last(dev, shape, frame, lo, sigma, masked, F1):
+    """The same with channels_last tiles: the channels_last-native single-launch kernel (single flow, chains spread over the
+    work-group, masks off, ratio branch, several items per work-group) and the tiled path."""
+    _lazy_vs_dense(dev, shape, frame, lo, sigma, masked, F1, True)
+
+
+def _lazy_vs_dense(dev, shape, frame, lo, sigma, masked, F1, nhwc):
     import types
     from contrast import ops, util
     from recipes import crop_coords, smooth_flow
     N, C, H, W = shape
     gen = torch.Generator().manual_seed(31 + N + H)
     rng = random.Random(5)
-    t = lambda: torch.randn(N, C, H, W, generator=gen).to(dev)
+    mf = torch.channels_last if nhwc else torch.contiguous_format
+    t = lambda: torch.randn(N, C, H, W, generator=gen).to(dev).contiguous(memory_format=mf)
     x1, v1, x2, v2, k1, k2 = t(), t(), t(), t(), t(), t()
     c1 = crop_coords(N, frame[1], frame[0], rng).to(dev)
     c2 = (c1 + 0.0).clone()
@@ -431,7 +449,7 @@ def test_lazy_flow_equals_dense(dev, shape, frame, lo, sigma, masked, F1):
     assert isinstance(lazy_f[0], util.LazyFlow) and (lazy_f[2] is None) == (not masked)
 
     def run(ff, fb):
-        xs = [z.clone().requires_grad_(True) for z in (x1, v1, x2, v2)]
+        xs = [z.clone(memory_format=torch.preserve_format).requires_grad_(True) for z in (x1, v1, x2, v2)]
         d1 = ops.Direction(xs[0], xs[1], k2, c1, c2, ff[0], ff[2] if not isinstance(ff[0], util.LazyFlow) else None, ff[1])
         d2 = ops.Direction(xs[2], xs[3], k1, c2, c1, fb[0], fb[2] if not isinstance(fb[0], util.LazyFlow) else None, fb[1])
         out = ops.ppm_loss([d1, d2], 2.0, 0.0, 0.7, True)
