@@ -110,7 +110,9 @@ __device__ __forceinline__ float cnt_of(const float* __restrict__ cnt, int b) {
 //   work-groups [6 B, 6 B + PREP_S B):  sample points (flow-displaced bin centres), positive-pair BIT rows, counts; every
 //                                work-group of a pair takes every PREP_S-th group of 4 rows
 __global__ void __launch_bounds__(TB) k_tl_pre(pixpro_problem pb, Dirs D, TlWs w) {
-  __shared__ __attribute__((aligned(16))) float pts[5 * TL_MAXP];
+  constexpr int PXB = 112, TRS = PXB + 1;       // channels_last transposition: pixels per block; odd row stride
+  constexpr int PTS = 5 * TL_MAXP > 64 * TRS + PXB ? 5 * TL_MAXP : 64 * TRS + PXB;
+  __shared__ __attribute__((aligned(16))) float pts[PTS];
   float *qx = pts, *qy = pts + TL_MAXP, *kx = pts + 2 * TL_MAXP, *ky = pts + 3 * TL_MAXP;
   int* valid = reinterpret_cast<int*>(pts + 4 * TL_MAXP);
   __shared__ float sT;
@@ -129,12 +131,12 @@ __global__ void __launch_bounds__(TB) k_tl_pre(pixpro_problem pb, Dirs D, TlWs w
     if (pb.layout == 1) {
       // channels_last input: the sample is [P][C].  This work-group owns the pixels [4 c0, 4 (c0 + fw)) with ALL channels:
       // the norms are sums over one contiguous 1-KB row per pixel, and since every element passes through here anyway the
-      // [C][P] image the products read is written on the way (transposed through LDS, 64 channels x up to 64 pixels at a
+      // [C][P] image the products read is written on the way (transposed through LDS, 64 channels x up to 112 pixels at a
       // time; rows of the image leave as 16 B per lane) - no layout copies on the host side.
       float* img = (which == 0 ? w.xT : which == 1 ? w.vT : w.kT) + (size_t)b * C * P;
-      constexpr int PXB = 64, TRS = PXB + 1;                  // pixels per block; odd row stride: conflict-free both ways
+      // 64 channels x up to PXB = 112 pixels at a time (a half of the 14 x 14 grid, 98 pixels, in one block: rows of the
+      // image leave as 392 contiguous bytes; round 4's first version used 64-pixel blocks: 44 us for the launch at N = 64)
       float* tr = pts;                                        // the point arrays are not in use in these work-groups
-      static_assert(64 * TRS + PXB <= 5 * TL_MAXP, "transposition tile fits in the point arrays");
       float* nrm = tr + 64 * TRS;                             // [PXB] sums of squares
       const int p0 = 4 * c0, npx = 4 * fw, pr = t >> 4, l4 = t & 15;
       const bool unit = which == 2 && !pb.normalize_k;

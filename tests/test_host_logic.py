@@ -300,3 +300,47 @@ def test_shipped_miopen_db_is_copied_not_written(monkeypatch):
     monkeypatch.setattr(mt, "_run_dir", None)
     monkeypatch.setenv("MIOPEN_USER_DB_PATH", "/somewhere/else")
     assert mt.use_shipped_db() is False and os.environ["MIOPEN_USER_DB_PATH"] == "/somewhere/else"
+
+
+def _bench_module():
+    import importlib.util
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    argv, sys.argv = sys.argv, ["bench.py"]
+    try:
+        spec.loader.exec_module(mod)
+    finally:
+        sys.argv = argv
+    return mod
+
+
+def test_bench_line_helpers():
+    """The pieces of the bench line that are pure host logic: algorithmic work per launch, the fractions, the
+    attainable bound and the PMC figures (kept summaries, filtered to kernels the built library still contains)."""
+    b = _bench_module()
+    assert b._mangled_fragment("k_tl_strip<2, 0, 8>") == b"10k_tl_stripILi2ELi0ELi8EE"
+    assert b._mangled_fragment("ppm_nhwc_kernel") == b"15ppm_nhwc_kernel"
+    a = types.SimpleNamespace(image_size=224, n_frames=2, batch=256, arch="resnet50", overlap_momentum=True)
+    ms = {"flow_prepare": 0.8, "ppm_loss": 0.08, "lars_sgd_step": 0.185, "ema_update": 0.076}
+    k = b.hot_kernel_lines(a, ms)
+    assert k["ppm_loss"]["algorithmic_flops_per_launch"] == 24 * 256 * 49 * 49 * 256
+    assert abs(k["ppm_loss"]["frac"] - 24 * 256 * 49 * 49 * 256 / 0.08e-3 / 157.3e12) < 1e-3
+    assert k["flow_prepare"]["algorithmic_bytes_per_launch"] == int((720 * 1280 * 4 / 16 + 4.5 * 720 * 1280 * 4) * 256)
+    assert all(0 < v["frac"] < 1 for v in k.values())
+    att = k["ppm_loss"].get("attainable")
+    if att is not None:                              # present when the library is built and a PMC summary is kept
+        assert att["kernel"] in ("ppm_nhwc_kernel", "ppm_fused_kernel") and 0 < att["frac_of_attainable"] < 1
+    util = k["ppm_loss"]["mfma_util_pmc_percent"]
+    if util:                                         # only kernels the library still launches
+        live = b._lib_bytes()
+        assert all(b._mangled_fragment(name) in live for name in util)
+    a6 = types.SimpleNamespace(image_size=224, n_frames=6, batch=64, arch="resnet50", overlap_momentum=True)
+    k6 = b.hot_kernel_lines(a6, {"flow_prepare": 2.5, "ppm_loss": 0.045})
+    vi = k6["flow_prepare"].get("valu_issue")
+    if vi:
+        assert vi["bound"] == "valu_issue" and 0.5 < vi["frac"] < 1.0
+    a5 = types.SimpleNamespace(image_size=448, n_frames=2, batch=64, arch="resnet50", overlap_momentum=True)
+    k5 = b.hot_kernel_lines(a5, {"ppm_loss": 0.296})
+    assert k5["ppm_loss"]["algorithmic_flops_per_launch"] == 24 * 256 * 196 * 196 * 64 and "attainable" not in k5["ppm_loss"]
