@@ -32,7 +32,7 @@ int run_fused(const pixpro_problem& pb, const pixpro_dir* dirs, float* loss_n, f
               hipStream_t st);
 bool fused_nhwc_supported(const pixpro_problem& pb);
 int run_fused_nhwc(const pixpro_problem& pb, const pixpro_dir* dirs, float* loss_n, float* pos_num, float* pos_mean,
-                   hipStream_t st);
+                   float* loss, int* folded, hipStream_t st);
 size_t generic_workspace_bytes(const pixpro_problem& pb);
 bool tiled_supported(const pixpro_problem& pb);
 size_t tiled_workspace_bytes(const pixpro_problem& pb);
@@ -157,9 +157,13 @@ int pixpro_ppm_loss(const pixpro_problem* pb, const pixpro_dir* dirs, float* los
                "(C in {64, 128, 256}, P % 4 == 0) only, 16-B aligned: see pixpro_ppm_loss_layout_supported");
   if (fused_supported(*pb) && aligned) {
     // channels_last tiles of the 7 x 7 grid at C = 256 (what the pre-training step runs): the NHWC-native persistent kernel
-    if (int e = fused_nhwc_supported(*pb) ? run_fused_nhwc(*pb, dirs, loss_n, pos_num, pos_mean, (hipStream_t)stream)
-                                          : run_fused(*pb, dirs, loss_n, pos_num, pos_mean, (hipStream_t)stream))
+    // (that kernel also folds the per-sample losses into `loss`: one launch for the whole op)
+    int folded = 0;
+    if (int e = fused_nhwc_supported(*pb)
+                    ? run_fused_nhwc(*pb, dirs, loss_n, pos_num, pos_mean, loss, &folded, (hipStream_t)stream)
+                    : run_fused(*pb, dirs, loss_n, pos_num, pos_mean, (hipStream_t)stream))
       return e;
+    if (folded) return PIXPRO_OK;
     return run_finalize(loss_n, loss, pb->N * pb->ndir, pb->N, (hipStream_t)stream);
   }
   if (!workspace) return bad("this shape takes a multi-launch path and needs a workspace");

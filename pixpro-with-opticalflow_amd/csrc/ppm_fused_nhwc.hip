@@ -27,6 +27,10 @@
 // :92-247 (regression_loss), :46-89 (add_optical_flow).
 #include "ppm_fused_shared.h"
 
+#include <map>
+#include <mutex>
+#include <unordered_map>
+
 namespace pixpro {
 
 #ifdef PIXPRO_STAMPS   // diagnostic build only (tools/ppm_phase_stamps.py --nhwc): wave 0 of the last work-group stamps s_memtime
@@ -754,7 +758,8 @@ __device__ __forceinline__ void nhwc_item(const pixpro_problem& pb, dirs_kernarg
     if (lane == 0) t += tce;
     t = wave_sum_valu(t);
     if (lane == 0) {
-      loss_n[b] = t / den;
+      // (write-through at agent scope: the work-group that folds the per-sample losses reads it on another XCD, see the kernel tail)
+      __hip_atomic_store(loss_n + b, t / den, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       pos_num[b] = cnt;
       pos_mean[b] = cnt / (float)P / (float)P;
     }
@@ -994,7 +999,7 @@ __device__ __forceinline__ void nhwc_item(const pixpro_problem& pb, dirs_kernarg
 
 __global__ void __launch_bounds__(NTHREADS)
 ppm_nhwc_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* __restrict__ pos_num,
-                float* __restrict__ pos_mean, int nitems) {
+                float* __restrict__ pos_mean, int nitems, float* __restrict__ loss, unsigned* __restrict__ ticket) {
   extern __shared__ __attribute__((aligned(16))) float smem_raw[];
   const Smem sm = carve(smem_raw);
   // kernel-argument segment: pb at offset 0, D right behind it (both 8-byte aligned)
@@ -1008,13 +1013,37 @@ ppm_nhwc_kernel(pixpro_problem pb, Dirs D, float* __restrict__ loss_n, float* __
 #endif
   for (int e = tid; e < (TROWS - P) * TS; e += NTHREADS) { sm.T[P * TS + e] = 0.f; sm.T[TILE + P * TS + e] = 0.f; }
   int b = blockIdx.x;
-  if (b >= nitems) return;
-  tile_dma(lane_ctx(), D.d[b / pb.N].x + (size_t)(b % pb.N) * (C * P), sm.T);
-  int flip = 0;
+  if (b < nitems) {
+    tile_dma(lane_ctx(), D.d[b / pb.N].x + (size_t)(b % pb.N) * (C * P), sm.T);
+    int flip = 0;
 #pragma clang loop unroll(disable)
-  for (; b < nitems; b += gridDim.x) {
-    nhwc_item(pb, Dp, loss_n, pos_num, pos_mean, b, nitems, flip);
-    flip ^= 1;
+    for (; b < nitems; b += gridDim.x) {
+      nhwc_item(pb, Dp, loss_n, pos_num, pos_mean, b, nitems, flip);
+      flip ^= 1;
+    }
+  }
+  // ---- loss = -2 * sum_d mean_n loss_n (PixPro.py:247,431) by the work-group that finishes last: no second launch ----
+  // Wave 0 wrote this work-group's loss_n entries (lane 0, write-through stores at agent scope).  vmcnt(0) = those stores are
+  // acknowledged at the device's coherence point; only then the ticket is drawn.  The work-group that draws the last ticket
+  // reads all entries back with agent-scope loads (they bypass this XCD's L2, which may hold the neighbours of its own entries
+  // in the same line), adds them in a fixed order and puts the ticket back to zero for the next launch on the stream.
+  // No cache write-back or invalidate anywhere: the only data that crosses work-groups is read and written past the L2.
+  if (ticket && tid < WAVE) {
+    int last = 0;
+    if (tid == 0) {
+      wait_vm<0>();
+      last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    }
+    if (__builtin_amdgcn_readfirstlane(last)) {
+      float acc = 0.f;
+      for (int e = tid; e < nitems; e += WAVE)
+        acc += __hip_atomic_load(loss_n + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      acc = wave_sum_valu(acc);
+      if (tid == 0) {
+        *loss = -2.f * acc / (float)pb.N;
+        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
   }
 }
 
@@ -1024,8 +1053,45 @@ bool fused_nhwc_supported(const pixpro_problem& pb) {
   return pb.layout == 1 && pb.H * pb.W == P && pb.C == C && !getenv("PIXPRO_NO_NHWC_KERNEL");
 }
 
+// One ticket word per (device, stream): launches on one stream run one after the other, so the word is back at zero when the
+// next one starts; launches on different streams never share a word.  The pool is allocated on first use (never while the
+// stream is being captured into a graph: nullptr then, and the caller falls back to the separate k_finalize launch).
+namespace {
+constexpr int TICKET_SLOTS = 4096;
+struct TicketPool {
+  unsigned* base = nullptr;
+  std::unordered_map<hipStream_t, int> slot;
+};
+unsigned* ticket_for(hipStream_t st) {
+  static std::mutex mu;
+  static std::map<int, TicketPool> pools;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> g(mu);
+  TicketPool& pool = pools[dev];
+  if (!pool.base) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
+    unsigned* p = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&p), TICKET_SLOTS * sizeof(unsigned)) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, TICKET_SLOTS * sizeof(unsigned)) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) {
+      (void)hipFree(p);
+      return nullptr;
+    }
+    pool.base = p;
+  }
+  auto it = pool.slot.find(st);
+  if (it == pool.slot.end()) {
+    if ((int)pool.slot.size() >= TICKET_SLOTS) return nullptr;
+    it = pool.slot.emplace(st, (int)pool.slot.size()).first;
+  }
+  return pool.base + it->second;
+}
+}  // namespace
+
+// *folded = 1: `loss` has been written by the kernel itself (no k_finalize launch needed)
 int run_fused_nhwc(const pixpro_problem& pb, const pixpro_dir* dirs, float* loss_n, float* pos_num, float* pos_mean,
-                   hipStream_t st) {
+                   float* loss, int* folded, hipStream_t st) {
   Dirs D;
   for (int d = 0; d < PIXPRO_MAX_DIRS; ++d) D.d[d] = dirs[d < pb.ndir ? d : 0];
   const size_t bytes = SMEM_FLOATS * sizeof(float);
@@ -1051,7 +1117,10 @@ int run_fused_nhwc(const pixpro_problem& pb, const pixpro_dir* dirs, float* loss
   int grid = cus > 0 ? cus : 256;
   if (const char* e = getenv("PIXPRO_NHWC_GRID")) grid = atoi(e) > 0 ? atoi(e) : grid;      // tuning knob
   if (grid > items) grid = items;
-  hipLaunchKernelGGL(ppm_nhwc_kernel, dim3(grid), dim3(NTHREADS), bytes, st, pb, D, loss_n, pos_num, pos_mean, items);
+  unsigned* ticket = (loss && !getenv("PIXPRO_NHWC_NO_FOLD")) ? ticket_for(st) : nullptr;
+  *folded = ticket != nullptr;
+  hipLaunchKernelGGL(ppm_nhwc_kernel, dim3(grid), dim3(NTHREADS), bytes, st, pb, D, loss_n, pos_num, pos_mean, items, loss,
+                     ticket);
   return check_launch("ppm_nhwc_kernel");
 }
 

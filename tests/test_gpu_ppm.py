@@ -394,6 +394,45 @@ def test_nhwc_kernel_persistent_walk(dev, N):
     assert torch.equal(f[1], b[1]) and f[0].item() == b[0].item()
 
 
+def test_nhwc_kernel_folds_the_loss_in_the_same_launch(dev, monkeypatch):
+    """loss = -2 * sum_d mean_n loss_n (PixPro.py:247,431) is written by the work-group of ppm_nhwc_kernel that finishes
+    last (ticket per stream, put back to zero by that work-group): equal to the separate k_finalize launch
+    (PIXPRO_NHWC_NO_FOLD=1) to the last bits, the same on every repetition, and safe with two streams in flight."""
+    from contrast import ops
+
+    def forward(q):
+        with torch.no_grad():
+            d1 = ops.Direction(q["x1"], q["v1"], q["k2"], q["c1"], q["c2"], q["ff"], q["mf"], q["size"])
+            d2 = ops.Direction(q["x2"], q["v2"], q["k1"], q["c2"], q["c1"], q["fb"], q["mb"], q["size"])
+            return ops.ppm_loss([d1, d2], 2.0, 0.0, 0.7, True)
+
+    probs = [_channels_last(_random_problem(dev, N, 256, 7, 7, 90, 160, seed=7 + N), dev) for N in (3, 300)]
+    want = []
+    for q in probs:
+        N = q["x1"].shape[0]
+        f = forward(q)
+        ref = -2.0 * f[3].double().sum().item() / N
+        assert abs(f[0].item() - ref) <= 2e-6 * max(1.0, abs(ref))
+        monkeypatch.setenv("PIXPRO_NHWC_NO_FOLD", "1")
+        g = forward(q)
+        monkeypatch.delenv("PIXPRO_NHWC_NO_FOLD")
+        assert torch.equal(f[3], g[3]) and abs(f[0].item() - g[0].item()) <= 1e-6
+        for _ in range(3):                               # the ticket is back at zero after every launch
+            assert forward(q)[0].item() == f[0].item()
+        want.append(f[0].item())
+    # two streams, launches interleaved from the host and overlapping on the device: each stream has its own ticket
+    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    torch.cuda.synchronize(dev)
+    got = [[], []]
+    for it in range(12):
+        for k, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                got[k].append(forward(probs[k])[0])
+    torch.cuda.synchronize(dev)
+    for k in range(2):
+        assert all(t.item() == want[k] for t in got[k])
+
+
 @pytest.mark.parametrize("shape,frame,lo,sigma,masked,F1", [
     ((6, 256, 7, 7), (96, 128), (12, 16), 0.5, True, 1), ((4, 256, 7, 7), (720, 1280), (90, 160), 0.5, True, 1),
     ((4, 256, 7, 7), (96, 128), (12, 16), 6.0, True, 1), ((3, 128, 7, 7), (96, 128), (12, 16), 0.5, False, 1),

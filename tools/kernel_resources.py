@@ -13,7 +13,7 @@ CSRC = os.path.join(ROOT, "pixpro-with-opticalflow_amd", "csrc")
 def main():
     src = sys.argv[1]
     extra = sys.argv[2:]
-    path = src if os.path.exists(src) else os.path.join(CSRC, src)
+    path = os.path.abspath(src) if os.path.exists(src) else os.path.join(CSRC, src)
     cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off",
            "-Rpass-analysis=kernel-resource-usage", "-c", path, "-o", "/dev/null"] + extra
     out = subprocess.run(cmd, capture_output=True, text=True, cwd=os.path.dirname(path)).stderr
