@@ -1,6 +1,6 @@
 """Work-group counts of the fused BN kernels (PIXPRO_BN_CAPS) swept over the ResNet-50 layer shapes at N=256: one child
 process per setting (the library reads the variable once), per-step totals (4 forward + 2 backward encoder passes).
-usage: python tools/bn_sweep.py            (parent)    |    python tools/bn_sweep.py child"""
+usage: python tools/bn_sweep.py [--lib exp_libs/libX.so] [--caps 256,512,1024,512 ...]   (parent; child = one setting)"""
 import itertools
 import os
 import subprocess
@@ -15,6 +15,9 @@ SHAPES = [(64, 112, 1, 0), (64, 56, 6, 0), (256, 56, 4, 3), (128, 56, 1, 0), (12
 
 def child():
     import torch
+    if os.environ.get("BN_SWEEP_LIB"):          # a kernel-variant build of the library (exp_libs/), see --lib
+        from contrast import _native
+        _native.LIB_PATH = os.path.abspath(os.environ["BN_SWEEP_LIB"])
     from contrast.sync_bn import FusedSyncBatchNorm
     dev, N = "cuda", 256
     tot = {"fwd": 0.0, "bwd": 0.0}
@@ -42,7 +45,7 @@ def child():
                     fn()
                 torch.cuda.synchronize()
                 tot[name] += (time.perf_counter() - t0) / 5 * 1e3 * k
-    print(f"{os.environ.get('PIXPRO_BN_CAPS', 'default'):>20s}  fwd/pass {tot['fwd']:7.2f}  bwd/pass {tot['bwd']:7.2f}  "
+    print(f"{os.path.basename(os.environ.get('BN_SWEEP_LIB', 'in-tree')):>20s} {os.environ.get('PIXPRO_BN_CAPS', 'default'):>20s}  fwd/pass {tot['fwd']:7.2f}  bwd/pass {tot['bwd']:7.2f}  "
           f"per step {4 * tot['fwd'] + 2 * tot['bwd']:7.2f} ms", flush=True)
 
 
@@ -50,7 +53,13 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "child":
         child()
     else:
-        for caps in [(256, 512, 1024, 512), (192, 512, 1024, 512), (384, 512, 1024, 512), (256, 384, 1024, 512),
+        # --lib PATH: that build instead of the in-tree one; --caps a,b,c,d [a,b,c,d ...]: these settings only
+        if "--lib" in sys.argv:
+            os.environ["BN_SWEEP_LIB"] = sys.argv[sys.argv.index("--lib") + 1]
+        only = None
+        if "--caps" in sys.argv:
+            only = [tuple(int(v) for v in a.split(",")) for a in sys.argv[sys.argv.index("--caps") + 1:] if "," in a]
+        for caps in only or [(256, 512, 1024, 512), (192, 512, 1024, 512), (384, 512, 1024, 512), (256, 384, 1024, 512),
                      (256, 768, 1024, 512), (256, 512, 768, 512), (256, 512, 1024, 384), (256, 512, 1024, 768),
                      (320, 640, 1024, 640), (256, 512, 512, 512)]:
             env = dict(os.environ, PIXPRO_BN_CAPS=",".join(map(str, caps)))
