@@ -67,6 +67,11 @@ __device__ __forceinline__ Ctx lane_ctx() {
   c.tid = tid; c.wave = __builtin_amdgcn_readfirstlane(tid >> 6); c.lane = tid & 63; c.lr = c.lane & 15; c.lq = c.lane >> 4;
   return c;
 }
+// 1 / max(sqrt(t), 1e-12) = min(rsqrt(t), 1e12) on v_rsq_f32 (1 ulp) - two instructions instead of the ~20 of a correctly
+// rounded sqrt and a correctly rounded division.  A lane evaluates about a dozen of these per item (it re-derives the norms
+// it needs instead of waiting a barrier for somebody else's), which was a tenth of the kernel's vector-ALU instructions.
+// The contractions re-associate anyway (tolerances of DESIGN.md 2); t = 0, denormal or NaN give 1e12 either way.
+__device__ __forceinline__ float rnorm(float t) { return fminf(__builtin_amdgcn_rsqf(t), 1e12f); }
 __device__ __forceinline__ int swz(int p) { return (p >> 2) & 3; }
 // element (pixel p, channel c) of a tile
 __device__ __forceinline__ int tix(int p, int c) { return p * TS + ((((c >> 2) ^ swz(p))) << 2) + (c & 3); }
@@ -551,7 +556,7 @@ __device__ __forceinline__ void nhwc_item(const pixpro_problem& pb, dirs_kernarg
     return t;
   };
   const float n48 = row48(P - 1);
-  auto rxof = [&](int j) { return 1.f / fmaxf(sqrtf(j < 48 ? sm.nx2[j] : n48), 1e-12f); };
+  auto rxof = [&](int j) { return rnorm(j < 48 ? sm.nx2[j] : n48); };
   if (tid < 64) sm.rx[tid] = rxof(min(tid, P - 1));
   // ---- positive-pair bit mask: row i of M = ballot over j (PixPro.py:217-223); row i's point comes out of lane i ----
   {
@@ -616,7 +621,7 @@ __device__ __forceinline__ void nhwc_item(const pixpro_problem& pb, dirs_kernarg
     float t = 0.f;
 #pragma unroll
     for (int w = 0; w < NWAVES; ++w) t += sm.part0[w * 64 + tid];
-    sm.rv[tid] = 1.f / fmaxf(sqrtf(t), 1e-12f);
+    sm.rv[tid] = rnorm(t);
   }
   if (tid == 0) {
     float c = 0.f;
@@ -666,20 +671,20 @@ __device__ __forceinline__ void nhwc_item(const pixpro_problem& pb, dirs_kernarg
       float t = 0.f;
 #pragma unroll
       for (int w = 0; w < NWAVES; ++w) t += sm.part1[w * 64 + 16 * nn + lr];
-      ry[nn] = 1.f / fmaxf(sqrtf(t), 1e-12f);
+      ry[nn] = rnorm(t);
     }
     {
       float t = 0.f;
 #pragma unroll
       for (int w = 0; w < NWAVES; ++w) t += sm.part1[w * 64 + 48];
-      rye = 1.f / fmaxf(sqrtf(t), 1e-12f);
+      rye = rnorm(t);
     }
     float rkj = 1.f;
     if (pb.normalize_k) {
       float t = 0.f;
 #pragma unroll
       for (int w = 0; w < NWAVES; ++w) t += sm.part0[w * 64 + lane];
-      rkj = 1.f / fmaxf(sqrtf(t), 1e-12f);
+      rkj = rnorm(t);
     }
     sm.rkw[wave * 64 + lane] = rkj;         // wave-private
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -19,6 +19,14 @@ NAMES = ["start", "load x, tap issue", "S gemm, pts, v->LDS", "rx, maskbits", "r
          "dY", "dA gemm+epi", "symm", "dV gemm+epi", "store dv", "dX gemm+epi", "store dx"]
 
 
+def _has_symbol(lib, name):
+    try:
+        getattr(lib, name)
+        return True
+    except AttributeError:
+        return False
+
+
 def build(out):
     srcs = [os.path.join(PKG, "csrc", f) for f in ("capi.hip", "ppm_fused.hip", "ppm_fused_nhwc.hip", "ppm_generic.hip", "ppm_tiled.hip", "flow_prep.hip",
                                                    "multi_tensor.hip", "sync_bn.hip", "raft_corr.hip")]
@@ -87,7 +95,22 @@ def main():
             b_ = list(buf)[base:base + 32]
             print(f"{name} item, S phase from the top barrier (stamp 1): wave 0 crop records + centres {b_[22] - b_[1]}, taps requested "
                   f"{b_[23] - b_[1]}, threshold {b_[24] - b_[1]}, points done {b_[2] - b_[1]}; wave 1 tile done {b_[27] - b_[1]}; "
-                  f"wave 7 row 48 from {b_[28] - b_[1]} to {b_[29] - b_[1]}")
+                  f"wave 7 centres + threshold from {b_[28] - b_[1]} to {b_[29] - b_[1]}")
+        lib = _native.load()
+        if hasattr(lib, "pixpro_debug_wave_stamps") or _has_symbol(lib, "pixpro_debug_wave_stamps"):
+            # experimental builds only: every wave's clock at 16 events of the last item (when each wave ARRIVES somewhere
+            # tells which wave a barrier waits for)
+            wb = (ctypes.c_ulonglong * 128)()
+            assert lib.pixpro_debug_wave_stamps(wb) == 0
+            ev = ["top barrier passed", "S phase done (arrival)", "S epilogue done", "v norms published", "Y gemm done (arrival)",
+                  "Y norms published", "G gemm done (arrival)", "loss reduced", "dY published", "dA done (arrival)",
+                  "dV gemm done (arrival)", "dV reduced", "dv epilogue done", "x landed, dSs published", "dX gemm done (arrival)",
+                  "dX reduced"]
+            t0 = min(wb[0:8])
+            print("per-wave ticks since the top barrier, last item:")
+            print(f"{'event':>28s} " + " ".join(f"{'w' + str(k):>7s}" for k in range(8)))
+            for e in range(16):
+                print(f"{ev[e]:>28s} " + " ".join(f"{wb[8 * e + k] - t0:7d}" for k in range(8)))
         return
     st = list(buf)[:16]
     tot = st[15] - st[0]
