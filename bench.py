@@ -302,6 +302,11 @@ class BnAudit:
         "pixpro_bn_apply": (11, 12, lambda a: 2 + (a[3] is not None)),
         "pixpro_bn_backward_reduce": (7, 8, lambda a: 2 + (a[6] != 0 and a[3] is None)),
         "pixpro_bn_backward_apply": (12, 13, lambda a: 3 + (a[11] != 0 and a[3] is None) + (a[15] is not None)),
+        # the ReLU bit record (1/32 of a pass) in place of the saved output; the shortcut gradient handed over as (dy, bits)
+        "pixpro_bn_apply_bits": (10, 11, lambda a: 2 + (a[3] is not None) + 1 / 32),
+        "pixpro_bn_backward_reduce_bits": (5, 6, lambda a: 2 + 1 / 32),
+        "pixpro_bn_backward_apply_bits": (10, 11, lambda a: 3 + 1 / 32 + (a[13] is not None)),
+        "pixpro_bn_masked_add": (4, 5, lambda a: 2 + (a[0] is not None) + 1 / 32),
     }
 
     def __init__(self):
@@ -327,7 +332,7 @@ class BnAudit:
     def summary(self):
         out = {}
         for name, s, e, nbytes in self.rec:
-            o = out.setdefault(name.replace("pixpro_", ""), [0, 0.0, 0])
+            o = out.setdefault(name.replace("pixpro_", "").replace("_bits", ""), [0, 0.0, 0])
             o[0] += 1
             o[1] += s.elapsed_time(e)
             o[2] += nbytes

@@ -84,7 +84,8 @@ typedef struct pixpro_dir {
   float* dv;
 } pixpro_dir;
 
-int pixpro_version(void);            /* 100 * major + minor: 110 = round 2 (flow_prepare_ws added; nothing removed) */
+int pixpro_version(void);            /* 100 * major + minor: 110 = round 2 (flow_prepare_ws added), 120 = round 4 (BatchNorm
+                                         ReLU bit record added); nothing removed */
 const char* pixpro_last_error(void);
 
 /* ---- K1+K2+K3+K4 fused: PixPro.featprop (PixPro.py:339-363) + F.normalize (:380) +
@@ -249,6 +250,33 @@ int pixpro_bn_backward_apply(const float* dy, const float* x, const float* y, co
                              const float* mean, const float* invstd, const float* weight, const float* sums,
                              const float* counts, int32_t world, int64_t count_stride, int32_t relu, int64_t rows,
                              int32_t C, float* dx, float* dresidual, void* stream);
+
+/* ---- ReLU decisions as a bit record (1.2) ----
+ * Behind a residual add (the last BatchNorm of a ResNet unit, contrast/resnet.py: `out += identity; out = relu(out)`) the
+ * ReLU decision cannot be recomputed from x, and reading the saved output y for it costs the backward pass two more
+ * sweeps over the widest tensors of the network.  pixpro_bn_apply_bits is pixpro_bn_apply with relu = 1 that also
+ * writes the decisions, one bit per element (rows * C / 8 bytes, caller-owned, 16-byte aligned); the two _bits backward
+ * entry points read that record where the plain ones read y.  Same arithmetic, same results bit for bit.
+ * pixpro_bn_relu_bits_bytes: size of the record, 0 = this shape has none (C % 256 != 0): use the plain entry points. */
+size_t pixpro_bn_relu_bits_bytes(int64_t rows, int32_t C);
+int pixpro_bn_apply_bits(const float* gathered, int32_t world, const float* x, const float* residual,
+                         const float* weight, const float* bias, float* running_mean, float* running_var,
+                         float momentum, float eps, int64_t rows, int32_t C, float* y, float* mean,
+                         float* invstd, float* scale_shift, void* relu_bits, void* stream);
+int pixpro_bn_backward_reduce_bits(const float* dy, const float* x, const void* relu_bits, const float* mean,
+                                   const float* invstd, int64_t rows, int32_t C, void* workspace,
+                                   size_t workspace_bytes, float* sums, float* grad_weight, float* grad_bias,
+                                   void* stream);
+int pixpro_bn_backward_apply_bits(const float* dy, const float* x, const void* relu_bits, const float* mean,
+                                  const float* invstd, const float* weight, const float* sums,
+                                  const float* counts, int32_t world, int64_t count_stride, int64_t rows,
+                                  int32_t C, float* dx, float* dresidual, void* stream);
+/* out = a + dy * bit (a nullable).  The shortcut gradient of a residual unit, dresidual = dy masked by the ReLU decisions,
+ * need not be materialised by pixpro_bn_backward_apply_bits (pass dresidual = NULL): where autograd would add it to the
+ * convolution branch's gradient `a` (contrast/resnet.py: `out += identity`), this reads dy and the record instead; a
+ * BatchNorm on the shortcut (downsample.1) takes (dy, relu_bits) straight into its own _bits backward calls. */
+int pixpro_bn_masked_add(const float* a, const float* dy, const void* relu_bits, float* out, int64_t rows,
+                         int32_t C, void* stream);
 
 #ifdef __cplusplus
 }

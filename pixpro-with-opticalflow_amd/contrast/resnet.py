@@ -10,7 +10,7 @@ import math
 
 import torch.nn as nn
 
-from .sync_bn import bn_act
+from .sync_bn import bn_act, fork, residual_link
 
 ARCHS = {
     # name: (block, depths, extra kwargs)
@@ -59,12 +59,23 @@ class _Residual(nn.Module):
 
     def forward(self, x):
         # bn_act(bn, t, relu, residual) = relu?(bn(t) (+ residual)): one fused launch pair with FusedSyncBatchNorm
-        identity = x if self.downsample is None else self.downsample(x)
+        # link: with the fused modules the shortcut's gradient is never written as a tensor - the last BatchNorm hands (dy,
+        # ReLU bits) to `fork` (identity shortcut) or to the shortcut's own BatchNorm (sync_bn.ResidualLink)
+        link = residual_link(x, self.bn2 if self.kind == "basic" else self.bn3)
+        if self.downsample is None:
+            x, identity = fork(x, link) if link is not None else (x, x)
+        elif link is not None and getattr(self.downsample[-1], "fused", False):
+            identity = x
+            for m in self.downsample[:-1]:
+                identity = m(identity)
+            identity = bn_act(self.downsample[-1], identity, link_in=link)
+        else:
+            identity = self.downsample(x)
         out = bn_act(self.bn1, self.conv1(x), relu=True)
         if self.kind == "basic":
-            return bn_act(self.bn2, self.conv2(out), relu=True, residual=identity)
+            return bn_act(self.bn2, self.conv2(out), relu=True, residual=identity, link_out=link)
         out = bn_act(self.bn2, self.conv2(out), relu=True)
-        return bn_act(self.bn3, self.conv3(out), relu=True, residual=identity)
+        return bn_act(self.bn3, self.conv3(out), relu=True, residual=identity, link_out=link)
 
 
 class ResNet(nn.Module):

@@ -15,6 +15,7 @@ Parameter / buffer names are those of `nn.BatchNorm2d` (`weight, bias, running_m
 so checkpoints load either way.  Activations must be channels_last (the layout the encoders run in); CPU tensors raise.
 """
 import ctypes
+import os
 
 import torch
 import torch.distributed as dist
@@ -46,6 +47,8 @@ def _world(group):
 
 
 _VIEW_GROUPS = 1
+# PIXPRO_BN_RELU_BITS=0: keep reading the saved output for the ReLU decisions behind a residual add (A/B switch, tests)
+_RELU_BITS = os.environ.get("PIXPRO_BN_RELU_BITS", "1") != "0"
 
 
 class view_groups:
@@ -69,6 +72,74 @@ class view_groups:
         _VIEW_GROUPS = self.prev
 
 
+class ResidualLink:
+    """Carries the shortcut gradient of ONE residual unit from the unit's last BatchNorm to whatever produced the shortcut
+    tensor, WITHOUT materialising it.  That gradient is `dy` masked by the unit's ReLU decisions; with the bit record
+    (pixpro_bn_apply_bits) the last BatchNorm's backward hands over (dy, bits) instead of writing `dy * mask` for autograd
+    to add: the consumer - `fork` at the unit's input (identity shortcut) or the shortcut's own BatchNorm (downsample.1) -
+    reads dy and the bits in the pass it makes anyway.  One sweep over the unit's widest tensor less; same numbers bit for
+    bit (a masked gradient added, or read, is the same arithmetic).  The consumer sets `ready` in its forward (it runs
+    before the last BatchNorm's forward), so a producer never leaves a gradient with a consumer that is not there."""
+    __slots__ = ("ready", "_lazy")
+
+    def __init__(self):
+        self.ready = False
+        self._lazy = None
+
+    def push(self, dy, bits):
+        self._lazy = (dy, bits)
+
+    def pop(self):
+        lazy, self._lazy = self._lazy, None
+        return lazy
+
+
+# PIXPRO_BN_LAZY_SHORTCUT=0: the last BatchNorm of a unit writes the shortcut gradient as a tensor (A/B switch, tests)
+_LAZY_SHORTCUT = os.environ.get("PIXPRO_BN_LAZY_SHORTCUT", "1") != "0"
+
+
+def residual_link(x, last_bn):
+    """A link for the unit whose input is x and whose last BatchNorm is last_bn, or None when it cannot be used."""
+    if _LAZY_SHORTCUT and _RELU_BITS and getattr(last_bn, "fused", False) and last_bn.training \
+            and torch.is_grad_enabled() and x.requires_grad and x.is_cuda:
+        return ResidualLink()
+    return None
+
+
+class _Fork(torch.autograd.Function):
+    """x -> (x, x): the unit's input goes to its first convolution and to the shortcut.  Backward adds the two gradients
+    as autograd would - except that the shortcut's may arrive over the link as (dy, bits)."""
+
+    @staticmethod
+    def forward(ctx, x, link):
+        ctx.link = link
+        ctx.set_materialize_grads(False)
+        link.ready = True
+        return x.view_as(x), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        lazy = ctx.link.pop()
+        base = ga if gb is None else (gb if ga is None else ga + gb)
+        if lazy is None:
+            return base, None
+        dy, bits = lazy
+        G = bits.shape[0]
+        C = dy.shape[1]
+        rows = dy.numel() // C // G
+        if base is not None and not base.is_contiguous(memory_format=torch.channels_last):
+            base = base.contiguous(memory_format=torch.channels_last)
+        out = torch.empty_like(dy)
+        for g in range(G):
+            nv.call("pixpro_bn_masked_add", nv.ptr(_part(base, g, G)), nv.ptr(_part(dy, g, G)), nv.ptr(bits[g]),
+                    nv.ptr(_part(out, g, G)), rows, C, nv.stream())
+        return out, None
+
+
+def fork(x, link):
+    return _Fork.apply(x, link)
+
+
 def _part(t, g, G):
     """View g of G along the batch dimension (a contiguous block of rows in channels_last / row-major storage)."""
     if t is None or G == 1:
@@ -79,7 +150,8 @@ def _part(t, g, G):
 
 class _FusedBN(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, running_mean, running_var, momentum, eps, relu, group, G):
+    def forward(ctx, x, weight, bias, residual, running_mean, running_var, momentum, eps, relu, group, G, grad_mode=True,
+                link_out=None, link_in=None):
         x, rows, C = _rows_view(x, "input")
         if not x.is_cuda or x.dtype != torch.float32:
             raise RuntimeError("FusedSyncBatchNorm runs on fp32 GPU tensors only; there is no CPU fallback")
@@ -117,21 +189,54 @@ class _FusedBN(torch.autograd.Function):
         y = torch.empty_like(x)
         rest = small[G * (2 * C + 4):]
         mean, invstd, scale_shift = rest[:G * C].view(G, C), rest[G * C:2 * G * C].view(G, C), rest[2 * G * C:].view(G, 2 * C)
+        # The ReLU decision is recomputed from x in backward unless a residual entered it.  Then it is kept as a bit record
+        # (1/32 of the tensor) where the shape has one, so that backward does not read the output y twice for it; needed
+        # only when something upstream wants a gradient.
+        bits, bits_bytes = None, 0
+        if relu and residual is not None and _RELU_BITS and grad_mode and any(ctx.needs_input_grad[:4]):
+            bits_bytes = nv.load().pixpro_bn_relu_bits_bytes(rows, C)
+            if bits_bytes:
+                bits = torch.empty(G, bits_bytes, dtype=torch.uint8, device=dev)
         for g in range(G):         # view after view: the running statistics see the same sequence of updates as G passes
+            if bits is not None:
+                nv.call("pixpro_bn_apply_bits", nv.ptr(gathered[g]), world, nv.ptr(_part(x, g, G)),
+                        nv.ptr(_part(residual, g, G)), nv.ptr(weight), nv.ptr(bias), nv.ptr(running_mean),
+                        nv.ptr(running_var), float(momentum), float(eps), rows, C, nv.ptr(_part(y, g, G)), nv.ptr(mean[g]),
+                        nv.ptr(invstd[g]), nv.ptr(scale_shift[g]), nv.ptr(bits[g]), nv.stream())
+                continue
             nv.call("pixpro_bn_apply", nv.ptr(gathered[g]), world, nv.ptr(_part(x, g, G)), nv.ptr(_part(residual, g, G)),
                     nv.ptr(weight), nv.ptr(bias), nv.ptr(running_mean), nv.ptr(running_var), float(momentum), float(eps),
                     int(relu), rows, C, nv.ptr(_part(y, g, G)), nv.ptr(mean[g]), nv.ptr(invstd[g]), nv.ptr(scale_shift[g]),
                     nv.stream())
-        # the ReLU decision is recomputed from x in backward unless a residual entered it (then the output is needed)
-        ctx.save_for_backward(x, y if (relu and residual is not None) else None, weight, mean, invstd,
-                              scale_shift if (relu and residual is None) else None, gathered)
+        ctx.save_for_backward(x, y if (relu and residual is not None and bits is None) else None, weight, mean, invstd,
+                              scale_shift if (relu and residual is None) else None, gathered, bits)
         ctx.meta = (rows, C, bool(relu), residual is not None, group, world, G)
+        # the shortcut gradient over a ResidualLink: as its producer (this is the unit's last BatchNorm, the bits exist, the
+        # consumer has announced itself) and / or as its consumer (this is the BatchNorm on the shortcut: no ReLU, no residual)
+        ctx.lazy_out = link_out if (link_out is not None and link_out.ready and bits is not None
+                                    and ctx.needs_input_grad[3]) else None
+        ctx.lazy_in = None
+        if link_in is not None and not relu and residual is None and dev.type == "cuda" and x.dim() == 4 \
+                and nv.load().pixpro_bn_relu_bits_bytes(rows, C):
+            ctx.lazy_in = link_in
+            link_in.ready = True
+            ctx.set_materialize_grads(False)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, y, weight, mean, invstd, scale_shift, gathered = ctx.saved_tensors
+        x, y, weight, mean, invstd, scale_shift, gathered, bits = ctx.saved_tensors
         rows, C, relu, has_res, group, world, G = ctx.meta
+        if ctx.lazy_in is not None:
+            lazy = ctx.lazy_in.pop()
+            if lazy is not None:
+                # the unit's last BatchNorm left (its dy, its ReLU bits): this layer's dy is their product, never written
+                if dy is not None:
+                    raise RuntimeError("FusedSyncBatchNorm: a shortcut gradient arrived both as a tensor and over its link")
+                dy, bits = lazy
+                relu = True          # (the _bits entry points mask dy by the record; this layer itself has no ReLU)
+            elif dy is None:
+                return (None,) * 14
         if dy.dim() == 4 and not dy.is_contiguous(memory_format=torch.channels_last) or dy.dim() == 2 and not dy.is_contiguous():
             dy = dy.contiguous(memory_format=torch.channels_last) if dy.dim() == 4 else dy.contiguous()
         dev = x.device
@@ -145,6 +250,11 @@ class _FusedBN(torch.autograd.Function):
         gw = small[2 * G * C:3 * G * C].view(G, C) if need_w else None
         gb = small[3 * G * C:].view(G, C) if need_b else None
         for g in range(G):
+            if bits is not None:
+                nv.call("pixpro_bn_backward_reduce_bits", nv.ptr(_part(dy, g, G)), nv.ptr(_part(x, g, G)), nv.ptr(bits[g]),
+                        nv.ptr(mean[g]), nv.ptr(invstd[g]), rows, C, nv.ptr(ws), wsb, nv.ptr(sums[g]),
+                        nv.ptr(gw[g] if need_w else None), nv.ptr(gb[g] if need_b else None), nv.stream())
+                continue
             nv.call("pixpro_bn_backward_reduce", nv.ptr(_part(dy, g, G)), nv.ptr(_part(x, g, G)), nv.ptr(_part(y, g, G)),
                     nv.ptr(scale_shift[g] if scale_shift is not None else None), nv.ptr(mean[g]), nv.ptr(invstd[g]),
                     int(relu), rows, C, nv.ptr(ws), wsb, nv.ptr(sums[g]), nv.ptr(gw[g] if need_w else None),
@@ -152,13 +262,20 @@ class _FusedBN(torch.autograd.Function):
         if world > 1:
             dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)     # ONE collective for all views of the layer
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        dres = torch.empty_like(x) if (has_res and ctx.needs_input_grad[3]) else None
+        dres = torch.empty_like(x) if (has_res and ctx.needs_input_grad[3] and ctx.lazy_out is None) else None
+        if ctx.lazy_out is not None:
+            ctx.lazy_out.push(dy, bits)       # the consumer reads dy and the bits itself; nothing is written here
         if dx is None and dres is not None:
             dx = torch.empty_like(x)
         if dx is not None:
             for g in range(G):
                 # the total row count is the sum of what the ranks exchanged in forward (element 2C of each packed record)
                 counts = ctypes.c_void_p(gathered[g].data_ptr() + 2 * C * 4)
+                if bits is not None:
+                    nv.call("pixpro_bn_backward_apply_bits", nv.ptr(_part(dy, g, G)), nv.ptr(_part(x, g, G)), nv.ptr(bits[g]),
+                            nv.ptr(mean[g]), nv.ptr(invstd[g]), nv.ptr(weight), nv.ptr(sums[g]), counts, world, 2 * C + 1,
+                            rows, C, nv.ptr(_part(dx, g, G)), nv.ptr(_part(dres, g, G)), nv.stream())
+                    continue
                 nv.call("pixpro_bn_backward_apply", nv.ptr(_part(dy, g, G)), nv.ptr(_part(x, g, G)), nv.ptr(_part(y, g, G)),
                         nv.ptr(scale_shift[g] if scale_shift is not None else None), nv.ptr(mean[g]), nv.ptr(invstd[g]),
                         nv.ptr(weight), nv.ptr(sums[g]), counts, world, 2 * C + 1, int(relu), rows, C,
@@ -169,7 +286,7 @@ class _FusedBN(torch.autograd.Function):
         else:
             gw = gw[0] if need_w else None
             gb = gb[0] if need_b else None
-        return dx, gw, gb, dres, None, None, None, None, None, None, None
+        return dx, gw, gb, dres, None, None, None, None, None, None, None, None, None, None
 
 
 def _flush_counter_hook(module, prefix, keep_vars):
@@ -225,15 +342,16 @@ class FusedSyncBatchNorm(nn.modules.batchnorm._BatchNorm):
         if input.dim() not in (2, 4):
             raise ValueError(f"expected 2D or 4D input (got {input.dim()}D input)")
 
-    def forward(self, input, residual=None, relu=False):
+    def forward(self, input, residual=None, relu=False, link_out=None, link_in=None):
         self._check_input_dim(input)
         if self.training or not self.track_running_stats:
             if self.training and self.track_running_stats and self._buffers.get("num_batches_tracked") is not None:
                 self._nbt_pending += _VIEW_GROUPS
             rm = self.running_mean if (self.training and self.track_running_stats) else None
             rv = self.running_var if (self.training and self.track_running_stats) else None
+            # (grad mode is always off inside Function.forward: it is read here)
             return _FusedBN.apply(input, self.weight, self.bias, residual, rm, rv, self.momentum, self.eps, relu,
-                                  self.process_group, _VIEW_GROUPS)
+                                  self.process_group, _VIEW_GROUPS, torch.is_grad_enabled(), link_out, link_in)
         out = F.batch_norm(input, self.running_mean, self.running_var, self.weight, self.bias, False, 0.0, self.eps)
         if residual is not None:
             out = out + residual
@@ -257,10 +375,11 @@ class FusedSyncBatchNorm(nn.modules.batchnorm._BatchNorm):
         return out
 
 
-def bn_act(bn, x, relu=False, residual=None):
-    """`relu?(bn(x) (+ residual))` through the fused module when `bn` is one, through the stock ops otherwise."""
+def bn_act(bn, x, relu=False, residual=None, link_out=None, link_in=None):
+    """`relu?(bn(x) (+ residual))` through the fused module when `bn` is one, through the stock ops otherwise.
+    link_out / link_in: the unit's ResidualLink on its last BatchNorm / on the BatchNorm of its shortcut."""
     if getattr(bn, "fused", False):
-        return bn(x, residual, relu)
+        return bn(x, residual, relu, link_out, link_in)
     out = bn(x)
     if residual is not None:
         out = out + residual

@@ -62,16 +62,18 @@ int run_scale(float* buf, size_t n, const float* scale, hipStream_t st);
 int run_corr_lookup(const float* const* levels, int L, const float* coords, float* out, int B, int h, int w, int h2, int w2,
                     int radius, hipStream_t st);
 size_t bn_workspace_floats(int64_t M, int C);
+size_t bn_relu_bits_bytes(int64_t M, int C);
+int run_bn_masked_add(const float* a, const float* dy, const void* relu_bits, float* out, int64_t M, int C, hipStream_t st);
 int run_bn_stats(const float* x, int64_t M, int C, float* ws, float* packed, hipStream_t st);
 int run_bn_apply(const float* gathered, int W, const float* x, const float* res, const float* weight, const float* bias,
                  float* running_mean, float* running_var, float momentum, float eps, int relu, int64_t M, int C,
-                 float* y, float* mean, float* invstd, float* scale_shift, hipStream_t st);
-int run_bn_bwd_reduce(const float* dy, const float* x, const float* y, const float* scale_shift, const float* mean,
-                      const float* invstd, int relu, int64_t M, int C, float* ws, float* sums, float* grad_weight,
-                      float* grad_bias, hipStream_t st);
-int run_bn_bwd_apply(const float* dy, const float* x, const float* y, const float* scale_shift, const float* mean,
-                     const float* invstd, const float* weight, const float* sums, const float* counts, int world,
-                     int64_t count_stride, int relu, int64_t M, int C, float* dx, float* dres, hipStream_t st);
+                 float* y, float* mean, float* invstd, float* scale_shift, void* relu_bits, hipStream_t st);
+int run_bn_bwd_reduce(const float* dy, const float* x, const float* y, const float* scale_shift, const void* relu_bits,
+                      const float* mean, const float* invstd, int relu, int64_t M, int C, float* ws, float* sums,
+                      float* grad_weight, float* grad_bias, hipStream_t st);
+int run_bn_bwd_apply(const float* dy, const float* x, const float* y, const float* scale_shift, const void* relu_bits,
+                     const float* mean, const float* invstd, const float* weight, const float* sums, const float* counts,
+                     int world, int64_t count_stride, int relu, int64_t M, int C, float* dx, float* dres, hipStream_t st);
 
 namespace {
 
@@ -112,7 +114,7 @@ using namespace pixpro;
 
 extern "C" {
 
-int pixpro_version(void) { return 110; }   // 1.1: pixpro_flow_prepare_ws, pixpro_flow_prepare_workspace_bytes
+int pixpro_version(void) { return 120; }   // 1.1: pixpro_flow_prepare_ws, pixpro_flow_prepare_workspace_bytes; 1.2: the BatchNorm ReLU bit record
 
 const char* pixpro_last_error(void) { return g_err; }
 
@@ -333,7 +335,26 @@ int pixpro_bn_apply(const float* gathered, int32_t world, const float* x, const 
   if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)residual | (uintptr_t)scale_shift) & 15)
     return bad("x, y, residual, scale_shift must be 16-byte aligned");
   return run_bn_apply(gathered, world, x, residual, weight, bias, running_mean, running_var, momentum, eps, relu, rows, C,
-                      y, mean, invstd, scale_shift, (hipStream_t)stream);
+                      y, mean, invstd, scale_shift, nullptr, (hipStream_t)stream);
+}
+
+size_t pixpro_bn_relu_bits_bytes(int64_t rows, int32_t C) {
+  if (rows < 1 || C < 4 || (C & 3)) return 0;
+  return bn_relu_bits_bytes(rows, C);
+}
+
+int pixpro_bn_apply_bits(const float* gathered, int32_t world, const float* x, const float* residual, const float* weight,
+                         const float* bias, float* running_mean, float* running_var, float momentum, float eps,
+                         int64_t rows, int32_t C, float* y, float* mean, float* invstd, float* scale_shift,
+                         void* relu_bits, void* stream) {
+  if (!gathered || !x || !y || !mean || !invstd || !scale_shift || !relu_bits) return bad("null pointer");
+  if (world < 1) return bad("world must be >= 1");
+  if (int e = bn_shape_ok(rows, C)) return e;
+  if (!bn_relu_bits_bytes(rows, C)) return bad("batch norm: no ReLU bit record for this shape (pixpro_bn_relu_bits_bytes == 0)");
+  if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)residual | (uintptr_t)scale_shift | (uintptr_t)relu_bits) & 15)
+    return bad("x, y, residual, scale_shift, relu_bits must be 16-byte aligned");
+  return run_bn_apply(gathered, world, x, residual, weight, bias, running_mean, running_var, momentum, eps, 1, rows, C,
+                      y, mean, invstd, scale_shift, relu_bits, (hipStream_t)stream);
 }
 
 int pixpro_bn_backward_reduce(const float* dy, const float* x, const float* y, const float* scale_shift,
@@ -346,7 +367,20 @@ int pixpro_bn_backward_reduce(const float* dy, const float* x, const float* y, c
   if (int e = bn_shape_ok(rows, C)) return e;
   if (workspace_bytes < pixpro_bn_workspace_bytes(rows, C)) return bad("workspace too small");
   if (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)y | (uintptr_t)mean) & 15) return bad("dy, x, y, mean must be 16-byte aligned");
-  return run_bn_bwd_reduce(dy, x, y, scale_shift, mean, invstd, relu, rows, C, (float*)workspace, sums, grad_weight,
+  return run_bn_bwd_reduce(dy, x, y, scale_shift, nullptr, mean, invstd, relu, rows, C, (float*)workspace, sums, grad_weight,
+                           grad_bias, (hipStream_t)stream);
+}
+
+int pixpro_bn_backward_reduce_bits(const float* dy, const float* x, const void* relu_bits, const float* mean,
+                                   const float* invstd, int64_t rows, int32_t C, void* workspace, size_t workspace_bytes,
+                                   float* sums, float* grad_weight, float* grad_bias, void* stream) {
+  if (!dy || !x || !relu_bits || !mean || !invstd || !workspace || !sums) return bad("null pointer");
+  if (int e = bn_shape_ok(rows, C)) return e;
+  if (!bn_relu_bits_bytes(rows, C)) return bad("batch norm: no ReLU bit record for this shape (pixpro_bn_relu_bits_bytes == 0)");
+  if (workspace_bytes < pixpro_bn_workspace_bytes(rows, C)) return bad("workspace too small");
+  if (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)relu_bits | (uintptr_t)mean) & 15)
+    return bad("dy, x, relu_bits, mean must be 16-byte aligned");
+  return run_bn_bwd_reduce(dy, x, nullptr, nullptr, relu_bits, mean, invstd, 1, rows, C, (float*)workspace, sums, grad_weight,
                            grad_bias, (hipStream_t)stream);
 }
 
@@ -362,9 +396,32 @@ int pixpro_bn_backward_apply(const float* dy, const float* x, const float* y, co
   if (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)y | (uintptr_t)dx | (uintptr_t)dresidual | (uintptr_t)mean |
        (uintptr_t)invstd | (uintptr_t)weight | (uintptr_t)sums) & 15)
     return bad("batch norm backward operands must be 16-byte aligned");
-  return run_bn_bwd_apply(dy, x, y, scale_shift, mean, invstd, weight, sums, counts, world, count_stride, relu, rows, C, dx,
-                          dresidual,
-                          (hipStream_t)stream);
+  return run_bn_bwd_apply(dy, x, y, scale_shift, nullptr, mean, invstd, weight, sums, counts, world, count_stride, relu, rows,
+                          C, dx, dresidual, (hipStream_t)stream);
+}
+
+int pixpro_bn_backward_apply_bits(const float* dy, const float* x, const void* relu_bits, const float* mean,
+                                  const float* invstd, const float* weight, const float* sums, const float* counts,
+                                  int32_t world, int64_t count_stride, int64_t rows, int32_t C, float* dx,
+                                  float* dresidual, void* stream) {
+  if (!dy || !x || !relu_bits || !mean || !invstd || !sums || !dx) return bad("null pointer");
+  if (!counts || world < 1 || count_stride < 1) return bad("counts / world / count_stride: the ranks' row counts are required");
+  if (int e = bn_shape_ok(rows, C)) return e;
+  if (!bn_relu_bits_bytes(rows, C)) return bad("batch norm: no ReLU bit record for this shape (pixpro_bn_relu_bits_bytes == 0)");
+  if (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)relu_bits | (uintptr_t)dx | (uintptr_t)dresidual | (uintptr_t)mean |
+       (uintptr_t)invstd | (uintptr_t)weight | (uintptr_t)sums) & 15)
+    return bad("batch norm backward operands must be 16-byte aligned");
+  return run_bn_bwd_apply(dy, x, nullptr, nullptr, relu_bits, mean, invstd, weight, sums, counts, world, count_stride, 1, rows,
+                          C, dx, dresidual, (hipStream_t)stream);
+}
+
+int pixpro_bn_masked_add(const float* a, const float* dy, const void* relu_bits, float* out, int64_t rows, int32_t C,
+                         void* stream) {
+  if (!dy || !relu_bits || !out) return bad("null pointer");
+  if (int e = bn_shape_ok(rows, C)) return e;
+  if (!bn_relu_bits_bytes(rows, C)) return bad("batch norm: no ReLU bit record for this shape (pixpro_bn_relu_bits_bytes == 0)");
+  if (((uintptr_t)a | (uintptr_t)dy | (uintptr_t)relu_bits | (uintptr_t)out) & 15) return bad("operands must be 16-byte aligned");
+  return run_bn_masked_add(a, dy, relu_bits, out, rows, C, (hipStream_t)stream);
 }
 
 }  // extern "C"

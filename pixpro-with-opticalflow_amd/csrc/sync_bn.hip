@@ -12,6 +12,9 @@
 //             k_apply: y = relu?( (x-mean)*invstd*w + b (+ residual) )                      (read x [,res], write y)
 //   backward  k_bwd_reduce: dz = dy * (y > 0)?; sum dz, sum dz*(x-mean) -> k_bwd_finalize      (read dy, x [,y]; same option)
 //             -> [all_reduce of 2C floats] -> k_bwd_apply: dx [, dres = dz]                   (read dy, x [,y])
+//   ReLU decisions behind a residual add (the last BatchNorm of a ResNet unit) cannot be recomputed from x alone; instead of
+//   reading the saved output y twice in backward (two passes over the widest tensors of the net), k_apply can leave them
+//   as a BIT RECORD - 1/32 of the tensor - which both backward kernels read (relu_bits, MODE 3).
 //
 // Statistics are accumulated as shifted sums (pivot = the channel's first element), so the variance does not suffer
 // the E[x^2]-E[x]^2 cancellation; partial sums are combined in a fixed order (deterministic; the only atomic is the ticket
@@ -48,7 +51,8 @@ inline BnCaps bn_caps() {
       int a, b, d, f;
       if (sscanf(e, "%d,%d,%d,%d", &a, &b, &d, &f) == 4) {
         auto cl = [](int v) { return std::min(std::max(v, 1), CAP_MAX); };
-        c = BnCaps{cl(a), cl(b), cl(d), cl(f)};
+        auto cw = [](int v) { return std::min(std::max(v, 1), 65535); };      // no workspace behind the element-wise kernels
+        c = BnCaps{cl(a), cw(b), cl(d), cw(f)};
       }
     }
     return c;
@@ -78,15 +82,34 @@ inline BnTile bn_tile(int64_t M, int C4, int cap) {
 __device__ __forceinline__ float4 ld4(const float* p, int64_t i4) { return reinterpret_cast<const float4*>(p)[i4]; }
 __device__ __forceinline__ void st4(float* p, int64_t i4, float4 v) { reinterpret_cast<float4*>(p)[i4] = v; }
 
+// Row walk of a work-group: the four rows a thread has in flight are gridDim.y * TY rows apart.  (Four ADJACENT row blocks
+// per thread - 16 KB contiguous per work-group and iteration at C = 256 - measure the same: 57.6 against 58.0 ms of
+// BatchNorm per step at their best work-group counts, round 4.)
+#define BN_WALK                                                                         \
+  const int64_t step = (int64_t)gridDim.y * TY, jump = 4 * step;                        \
+  int64_t r = (int64_t)blockIdx.y * TY + ty;
 #define BN_ROWS(body)                                                                   \
   const int tx = threadIdx.x & (TX - 1), ty = threadIdx.x / TX;                         \
   const int c4 = blockIdx.x * TX + tx;                                                  \
-  const int64_t step = (int64_t)gridDim.y * TY;                                         \
-  int64_t r = (int64_t)blockIdx.y * TY + ty;                                            \
-  for (; r + 3 * step < M; r += 4 * step) {                                             \
+  BN_WALK                                                                               \
+  for (; r + 3 * step < M; r += jump) {                                                 \
     body(r) body(r + step) body(r + 2 * step) body(r + 3 * step)                        \
   }                                                                                     \
-  for (; r < M; r += step) { body(r) }
+  for (int k_ = 0; k_ < 4 && r + k_ * step < M; ++k_) { body(r + k_ * step) }
+
+// The same walk with the loads of the four rows issued together, in front of a scheduling barrier: left to itself hipcc
+// emits the backward kernels as load - wait - use - store per row (one row in flight per thread, and with the bit record a
+// second dependent round trip per row).  LOAD(k, row) declares what row slot k needs, USE(k, row) consumes it.
+#define BN_ROWS_LU(LOAD, USE)                                                           \
+  const int tx = threadIdx.x & (TX - 1), ty = threadIdx.x / TX;                         \
+  const int c4 = blockIdx.x * TX + tx;                                                  \
+  BN_WALK                                                                               \
+  for (; r + 3 * step < M; r += jump) {                                                 \
+    LOAD(0, r) LOAD(1, r + step) LOAD(2, r + 2 * step) LOAD(3, r + 3 * step)            \
+    __builtin_amdgcn_sched_barrier(0);                                                  \
+    USE(0, r) USE(1, r + step) USE(2, r + 2 * step) USE(3, r + 3 * step)                \
+  }                                                                                     \
+  for (int k_ = 0; k_ < 4 && r + k_ * step < M; ++k_) { LOAD(0, r + k_ * step) USE(0, r + k_ * step) }
 
 // reduce two float4 per thread over the TY rows of the block (fixed order) -> out0/out1 of the ty == 0 lanes
 __device__ __forceinline__ void block_rows_sum(float4& a, float4& b, int TX, int TY, float4* sh) {
@@ -288,12 +311,16 @@ __device__ __forceinline__ BnMerged merge_channel(const float* __restrict__ gath
 // gathered [W][2C+1] -> y = relu?(x * scale + shift (+ residual)).  Every work-group merges the statistics of its own
 // channels in its prologue (a few dozen flops per lane: cheaper than a separate launch per layer); the first row block
 // also publishes mean, invstd (saved for backward), scale/shift, and updates the running statistics (unbiased variance).
-template <bool RELU, bool RES>
+// BITS (needs TX == 64 and C4 % 64 == 0, so that a wave holds the 64 consecutive float4 i0 .. i0 + 63 of one row, i0 % 64 == 0):
+// the ReLU decisions of those 256 elements leave as one 32-byte record, bits[(i0 / 64) * 4 + k] bit l = component k of
+// float4 i0 + l is positive.  v_cmp produces the four words as they are; lanes 0..3 store them.
+template <bool RELU, bool RES, bool BITS>
 __global__ void __launch_bounds__(BN_TPB)
 k_apply(const float* __restrict__ gathered, int W, const float* __restrict__ weight, const float* __restrict__ bias,
         float* __restrict__ running_mean, float* __restrict__ running_var, float momentum, float eps,
         float* __restrict__ mean_out, float* __restrict__ invstd_out, float* __restrict__ scale_shift,
-        const float* __restrict__ x, const float* __restrict__ res, float* __restrict__ y, int64_t M, int C4, int TX, int TY) {
+        const float* __restrict__ x, const float* __restrict__ res, float* __restrict__ y,
+        unsigned long long* __restrict__ bits, int64_t M, int C4, int TX, int TY) {
   const int cc = blockIdx.x * TX + (threadIdx.x & (TX - 1));
   const int C = C4 * 4;
   const bool publish = blockIdx.y == 0 && threadIdx.x / TX == 0;
@@ -318,20 +345,35 @@ k_apply(const float* __restrict__ gathered, int W, const float* __restrict__ wei
     o.z = __builtin_fmaf(v.z, sc.z, sf.z); o.w = __builtin_fmaf(v.w, sc.w, sf.w);                              \
     if (RES) { const float4 e = ld4(res, i); o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w; }                 \
     if (RELU) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }  \
-    st4(y, i, o); }
+    st4(y, i, o);                                                                                             \
+    if (BITS) { const unsigned long long b0 = __ballot(o.x > 0.f), b1 = __ballot(o.y > 0.f),                   \
+                                         b2 = __ballot(o.z > 0.f), b3 = __ballot(o.w > 0.f);                   \
+                if (tx < 4) bits[(i >> 6) * 4 + tx] = tx == 0 ? b0 : tx == 1 ? b1 : tx == 2 ? b2 : b3; } }
   BN_ROWS(BODY)
 #undef BODY
 }
 
 // ReLU decision of the forward pass for one float4: MODE 1 reads the saved output y, MODE 2 recomputes it from x with
-// the forward's own scale / shift and the same fma (no residual in that case), MODE 0: no ReLU.
-#define BN_MASK(MODE, g, v, i)                                                                                 \
-    if (MODE == 1) { const float4 o = ld4(y, i); g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f;      \
-                     g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f; }                               \
+// the forward's own scale / shift and the same fma (no residual in that case), MODE 3 reads k_apply's bit record (`y`
+// then points at it; the record of a wave's 64 float4 is 32 bytes at one address: a broadcast load), MODE 0: no ReLU.
+// BN_MASK_LOAD issues what the decision needs from memory (slot k), BN_MASK_APPLY masks g.
+#define BN_MASK_LOAD(MODE, k, i)                                                                               \
+    float4 o##k = {0.f, 0.f, 0.f, 0.f}; uint4 p##k = {0u, 0u, 0u, 0u}, q##k = p##k;                             \
+    if (MODE == 1) o##k = ld4(y, i);                                                                           \
+    if (MODE == 3) { const uint4* bp_ = reinterpret_cast<const uint4*>(y) + ((i) >> 6) * 2;                     \
+                     p##k = bp_[0]; q##k = bp_[1]; }
+#define BN_MASK_APPLY(MODE, k, g, v)                                                                           \
+    if (MODE == 1) { g.x = o##k.x > 0.f ? g.x : 0.f; g.y = o##k.y > 0.f ? g.y : 0.f;                            \
+                     g.z = o##k.z > 0.f ? g.z : 0.f; g.w = o##k.w > 0.f ? g.w : 0.f; }                         \
     if (MODE == 2) { g.x = __builtin_fmaf(v.x, sc.x, sf.x) > 0.f ? g.x : 0.f;                                  \
                      g.y = __builtin_fmaf(v.y, sc.y, sf.y) > 0.f ? g.y : 0.f;                                  \
                      g.z = __builtin_fmaf(v.z, sc.z, sf.z) > 0.f ? g.z : 0.f;                                  \
-                     g.w = __builtin_fmaf(v.w, sc.w, sf.w) > 0.f ? g.w : 0.f; }
+                     g.w = __builtin_fmaf(v.w, sc.w, sf.w) > 0.f ? g.w : 0.f; }                                \
+    if (MODE == 3) { const int sh_ = tx & 31; const bool hi_ = tx >= 32;                                       \
+                     g.x = (((hi_ ? p##k.y : p##k.x) >> sh_) & 1u) ? g.x : 0.f;                                 \
+                     g.y = (((hi_ ? p##k.w : p##k.z) >> sh_) & 1u) ? g.y : 0.f;                                 \
+                     g.z = (((hi_ ? q##k.y : q##k.x) >> sh_) & 1u) ? g.z : 0.f;                                 \
+                     g.w = (((hi_ ? q##k.w : q##k.z) >> sh_) & 1u) ? g.w : 0.f; }
 
 // partial[by][0][C] = sum dz, partial[by][1][C] = sum dz * (x - mean);  dz = dy masked by the forward's ReLU decision
 template <int MODE>
@@ -346,13 +388,15 @@ k_bwd_reduce(const float* __restrict__ dy, const float* __restrict__ x, const fl
   const float4 mu = ld4(mean, cc);
   float4 sc = mu, sf = mu;
   if (MODE == 2) { sc = ld4(scale_shift, cc); sf = ld4(scale_shift + (int64_t)C4 * 4, cc); }
-#define BODY(row) { const int64_t i = (row) * C4 + c4; float4 g = ld4(dy, i); const float4 v = ld4(x, i);       \
-    BN_MASK(MODE, g, v, i)                                                                                     \
-    s.x += g.x; s.y += g.y; s.z += g.z; s.w += g.w;                                                            \
-    q.x = __builtin_fmaf(g.x, v.x - mu.x, q.x); q.y = __builtin_fmaf(g.y, v.y - mu.y, q.y);                    \
-    q.z = __builtin_fmaf(g.z, v.z - mu.z, q.z); q.w = __builtin_fmaf(g.w, v.w - mu.w, q.w); }
-  BN_ROWS(BODY)
-#undef BODY
+#define LOAD(k, row) const int64_t i##k = (row) * C4 + c4; float4 g##k = ld4(dy, i##k); const float4 v##k = ld4(x, i##k); \
+    BN_MASK_LOAD(MODE, k, i##k)
+#define USE(k, row) { BN_MASK_APPLY(MODE, k, g##k, v##k)                                                        \
+    s.x += g##k.x; s.y += g##k.y; s.z += g##k.z; s.w += g##k.w;                                                \
+    q.x = __builtin_fmaf(g##k.x, v##k.x - mu.x, q.x); q.y = __builtin_fmaf(g##k.y, v##k.y - mu.y, q.y);        \
+    q.z = __builtin_fmaf(g##k.z, v##k.z - mu.z, q.z); q.w = __builtin_fmaf(g##k.w, v##k.w - mu.w, q.w); }
+  BN_ROWS_LU(LOAD, USE)
+#undef LOAD
+#undef USE
   block_rows_sum(s, q, TX, TY, sh);
   const int64_t C = (int64_t)C4 * 4;
   if (ty == 0) {
@@ -402,17 +446,46 @@ k_bwd_apply(const float* __restrict__ dy, const float* __restrict__ x, const flo
   b.x = -(sx.x * inv_n) * is.x * is.x * a.x; b.y = -(sx.y * inv_n) * is.y * is.y * a.y;
   b.z = -(sx.z * inv_n) * is.z * is.z * a.z; b.w = -(sx.w * inv_n) * is.w * is.w * a.w;
   c.x = -(sd.x * inv_n) * a.x; c.y = -(sd.y * inv_n) * a.y; c.z = -(sd.z * inv_n) * a.z; c.w = -(sd.w * inv_n) * a.w;
-#define BODY(row) { const int64_t i = (row) * C4 + c4; float4 g = ld4(dy, i); const float4 v = ld4(x, i);       \
-    BN_MASK(MODE, g, v, i)                                                                                     \
-    if (RES) st4(dres, i, g);                                                                                 \
+#define LOAD(k, row) const int64_t i##k = (row) * C4 + c4; float4 g##k = ld4(dy, i##k); const float4 v##k = ld4(x, i##k); \
+    BN_MASK_LOAD(MODE, k, i##k)
+#define USE(k, row) { BN_MASK_APPLY(MODE, k, g##k, v##k)                                                        \
+    if (RES) st4(dres, i##k, g##k);                                                                           \
     float4 o2;                                                                                                \
-    o2.x = __builtin_fmaf(g.x, a.x, __builtin_fmaf(v.x - mu.x, b.x, c.x));                                    \
-    o2.y = __builtin_fmaf(g.y, a.y, __builtin_fmaf(v.y - mu.y, b.y, c.y));                                    \
-    o2.z = __builtin_fmaf(g.z, a.z, __builtin_fmaf(v.z - mu.z, b.z, c.z));                                    \
-    o2.w = __builtin_fmaf(g.w, a.w, __builtin_fmaf(v.w - mu.w, b.w, c.w));                                    \
-    st4(dx, i, o2); }
-  BN_ROWS(BODY)
-#undef BODY
+    o2.x = __builtin_fmaf(g##k.x, a.x, __builtin_fmaf(v##k.x - mu.x, b.x, c.x));                              \
+    o2.y = __builtin_fmaf(g##k.y, a.y, __builtin_fmaf(v##k.y - mu.y, b.y, c.y));                              \
+    o2.z = __builtin_fmaf(g##k.z, a.z, __builtin_fmaf(v##k.z - mu.z, b.z, c.z));                              \
+    o2.w = __builtin_fmaf(g##k.w, a.w, __builtin_fmaf(v##k.w - mu.w, b.w, c.w));                              \
+    st4(dx, i##k, o2); }
+  BN_ROWS_LU(LOAD, USE)
+#undef LOAD
+#undef USE
+}
+
+// out = a + dy * bit   (a nullable: out = dy * bit).  The gradient that reaches a residual unit's input is the sum of its
+// convolution branch's and of what the unit's last BatchNorm passes to the shortcut, dz = dy masked by the ReLU decisions:
+// with the bit record that term need not be written by k_bwd_apply and read back by an add - this kernel reads dy and the
+// bits instead (one pass over the widest tensors less per unit).  A wave holds 64 consecutive float4, i0 % 64 == 0.
+__global__ void __launch_bounds__(BN_TPB)
+k_masked_add(const float* __restrict__ a, const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ out,
+             int64_t n4) {
+  const int tx = threadIdx.x & 63;
+  const float4 sc = {0.f, 0.f, 0.f, 0.f}, sf = sc;       // (named by the other modes of BN_MASK_APPLY)
+  const int64_t step = (int64_t)gridDim.x * BN_TPB, jump = 4 * step;
+  int64_t i = (int64_t)blockIdx.x * BN_TPB + threadIdx.x;
+#define LOAD(k, idx) const int64_t i##k = (idx); float4 g##k = ld4(dy, i##k); float4 e##k = {0.f, 0.f, 0.f, 0.f};   \
+    if (a) e##k = ld4(a, i##k);                                                                               \
+    BN_MASK_LOAD(3, k, i##k)
+#define USE(k, idx) { BN_MASK_APPLY(3, k, g##k, g##k)                                                           \
+    g##k.x += e##k.x; g##k.y += e##k.y; g##k.z += e##k.z; g##k.w += e##k.w;                                    \
+    st4(out, i##k, g##k); }
+  for (; i + 3 * step < n4; i += jump) {
+    LOAD(0, i) LOAD(1, i + step) LOAD(2, i + 2 * step) LOAD(3, i + 3 * step)
+    __builtin_amdgcn_sched_barrier(0);
+    USE(0, i) USE(1, i + step) USE(2, i + 2 * step) USE(3, i + 3 * step)
+  }
+  for (int k_ = 0; k_ < 4 && i + k_ * step < n4; ++k_) { LOAD(0, i + k_ * step) USE(0, i + k_ * step) }
+#undef LOAD
+#undef USE
 }
 
 #define CHECKED(what)                         \
@@ -442,38 +515,56 @@ int run_bn_stats(const float* x, int64_t M, int C, float* ws, float* packed, hip
   return PIXPRO_OK;
 }
 
+// the bit record of the ReLU decisions: rows * C / 8 bytes; shapes whose waves do not hold 64 consecutive float4: 0
+size_t bn_relu_bits_bytes(int64_t M, int C) {
+  if (C % 256 || M * (int64_t)(C / 256) > 0x7fffffff) return 0;
+  return (size_t)M * (size_t)C / 8;
+}
+
 int run_bn_apply(const float* gathered, int W, const float* x, const float* res, const float* weight, const float* bias,
                  float* running_mean, float* running_var, float momentum, float eps, int relu, int64_t M, int C,
-                 float* y, float* mean, float* invstd, float* scale_shift, hipStream_t st) {
+                 float* y, float* mean, float* invstd, float* scale_shift, void* relu_bits, hipStream_t st) {
   const BnTile t = bn_tile(M, C / 4, bn_caps().apply);
   const dim3 g(t.gx, t.gy), b(BN_TPB);
-#define APPLY(R, S) hipLaunchKernelGGL((k_apply<R, S>), g, b, 0, st, gathered, W, weight, bias, running_mean, running_var, \
-                                       momentum, eps, mean, invstd, scale_shift, x, res, y, M, C / 4, t.TX, t.TY)
-  if (relu && res) APPLY(true, true);
-  else if (relu) APPLY(true, false);
-  else if (res) APPLY(false, true);
-  else APPLY(false, false);
+  unsigned long long* bits = static_cast<unsigned long long*>(relu_bits);
+#define APPLY(R, S, B) hipLaunchKernelGGL((k_apply<R, S, B>), g, b, 0, st, gathered, W, weight, bias, running_mean, running_var, \
+                                          momentum, eps, mean, invstd, scale_shift, x, res, y, bits, M, C / 4, t.TX, t.TY)
+  if (bits) {
+    if (!relu || t.TX != 64 || !bn_relu_bits_bytes(M, C)) return PIXPRO_ERR_ARG;
+    if (res) APPLY(true, true, true); else APPLY(true, false, true);
+  }
+  else if (relu && res) APPLY(true, true, false);
+  else if (relu) APPLY(true, false, false);
+  else if (res) APPLY(false, true, false);
+  else APPLY(false, false, false);
 #undef APPLY
   CHECKED("k_apply");
   return PIXPRO_OK;
 }
 
-// ReLU decision source: 0 none, 1 the saved output y, 2 recomputed from x (scale_shift given)
-static inline int mask_mode(int relu, const float* scale_shift) { return !relu ? 0 : (scale_shift ? 2 : 1); }
+// ReLU decision source: 0 none, 1 the saved output y, 2 recomputed from x (scale_shift given), 3 the bit record
+static inline int mask_mode(int relu, const float* scale_shift, const void* bits) {
+  return !relu ? 0 : (bits ? 3 : (scale_shift ? 2 : 1));
+}
 
-int run_bn_bwd_reduce(const float* dy, const float* x, const float* y, const float* scale_shift, const float* mean,
-                      const float* invstd, int relu, int64_t M, int C, float* ws, float* sums, float* grad_weight,
-                      float* grad_bias, hipStream_t st) {
+int run_bn_bwd_reduce(const float* dy, const float* x, const float* y, const float* scale_shift, const void* relu_bits,
+                      const float* mean, const float* invstd, int relu, int64_t M, int C, float* ws, float* sums,
+                      float* grad_weight, float* grad_bias, hipStream_t st) {
   const BnTile t = bn_tile(M, C / 4, bn_caps().bwd_reduce);
+  if (relu_bits) {
+    if (!relu || t.TX != 64 || !bn_relu_bits_bytes(M, C)) return PIXPRO_ERR_ARG;
+    y = static_cast<const float*>(relu_bits);        // MODE 3 reads the record through the `y` argument
+  }
   const dim3 g(t.gx, t.gy), b(BN_TPB);
   const bool fold = bn_fold_in_kernel();
 #define REDUCE(MD) hipLaunchKernelGGL((k_bwd_reduce<MD>), g, b, 0, st, dy, x, y, scale_shift, mean, invstd,                \
                                      fold ? reinterpret_cast<int*>(ws) : nullptr, ws + BN_HDR, sums, grad_weight, grad_bias, M, \
                                      C / 4, t.TX, t.TY)
-  switch (mask_mode(relu, scale_shift)) {
+  switch (mask_mode(relu, scale_shift, relu_bits)) {
     case 0: REDUCE(0); break;
     case 1: REDUCE(1); break;
-    default: REDUCE(2); break;
+    case 2: REDUCE(2); break;
+    default: REDUCE(3); break;
   }
 #undef REDUCE
   CHECKED("k_bwd_reduce");
@@ -485,18 +576,32 @@ int run_bn_bwd_reduce(const float* dy, const float* x, const float* y, const flo
   return PIXPRO_OK;
 }
 
-int run_bn_bwd_apply(const float* dy, const float* x, const float* y, const float* scale_shift, const float* mean,
-                     const float* invstd, const float* weight, const float* sums, const float* counts, int world,
-                     int64_t count_stride, int relu, int64_t M, int C, float* dx, float* dres, hipStream_t st) {
+int run_bn_bwd_apply(const float* dy, const float* x, const float* y, const float* scale_shift, const void* relu_bits,
+                     const float* mean, const float* invstd, const float* weight, const float* sums, const float* counts,
+                     int world, int64_t count_stride, int relu, int64_t M, int C, float* dx, float* dres, hipStream_t st) {
   const BnTile t = bn_tile(M, C / 4, bn_caps().bwd_apply);
+  if (relu_bits) {
+    if (!relu || t.TX != 64 || !bn_relu_bits_bytes(M, C)) return PIXPRO_ERR_ARG;
+    y = static_cast<const float*>(relu_bits);
+  }
   const dim3 g(t.gx, t.gy), b(BN_TPB);
 #define BAPPLY(MD, S) hipLaunchKernelGGL((k_bwd_apply<MD, S>), g, b, 0, st, dy, x, y, scale_shift, mean, invstd, weight, \
                                          sums, counts, world, count_stride, dx, dres, M, C / 4, t.TX, t.TY)
-  const int mode = mask_mode(relu, scale_shift);
-  if (dres) { if (mode == 0) BAPPLY(0, true); else if (mode == 1) BAPPLY(1, true); else BAPPLY(2, true); }
-  else { if (mode == 0) BAPPLY(0, false); else if (mode == 1) BAPPLY(1, false); else BAPPLY(2, false); }
+  const int mode = mask_mode(relu, scale_shift, relu_bits);
+  if (dres) { if (mode == 0) BAPPLY(0, true); else if (mode == 1) BAPPLY(1, true); else if (mode == 2) BAPPLY(2, true); else BAPPLY(3, true); }
+  else { if (mode == 0) BAPPLY(0, false); else if (mode == 1) BAPPLY(1, false); else if (mode == 2) BAPPLY(2, false); else BAPPLY(3, false); }
 #undef BAPPLY
   CHECKED("k_bwd_apply");
+  return PIXPRO_OK;
+}
+
+int run_bn_masked_add(const float* a, const float* dy, const void* relu_bits, float* out, int64_t M, int C, hipStream_t st) {
+  if (!bn_relu_bits_bytes(M, C)) return PIXPRO_ERR_ARG;
+  const int64_t n4 = M * (int64_t)(C / 4);
+  const int64_t blocks = std::min<int64_t>((n4 + (int64_t)BN_TPB * 4 - 1) / ((int64_t)BN_TPB * 4), 2048);
+  hipLaunchKernelGGL(k_masked_add, dim3((unsigned)std::max<int64_t>(blocks, 1)), dim3(BN_TPB), 0, st, a, dy,
+                     static_cast<const float*>(relu_bits), out, n4);
+  CHECKED("k_masked_add");
   return PIXPRO_OK;
 }
 

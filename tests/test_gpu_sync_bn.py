@@ -440,3 +440,156 @@ def test_partial_sum_fold_is_repeatable_and_stream_safe(dev, fold, monkeypatch):
     for buf in nv._zeroed.values():
         assert int(buf[:4096].view(torch.int32).abs().sum()) == 0          # every ticket back at zero
     assert len(nv._zeroed) >= 2                                           # one workspace per stream
+
+
+@pytest.mark.parametrize("shape", [(4, 256, 7, 7), (3, 2048, 7, 7), (16, 512, 28, 28), (7, 1024, 5, 3), (2, 256, 1, 1)])
+@pytest.mark.parametrize("groups", [1, 2])
+def test_relu_bit_record_equals_reading_the_output(dev, shape, groups, monkeypatch):
+    """Behind a residual add the ReLU decisions travel to backward as a bit record (pixpro_bn_apply_bits, 1/32 of the tensor)
+    instead of being read back from the saved output: every gradient must be BIT-identical to the y-reading kernels, for
+    row counts that leave tails in the row loops and with two views per pass."""
+    from contrast import sync_bn, _native
+    from contrast.sync_bn import FusedSyncBatchNorm, view_groups
+    N, C, H, W = shape
+    N *= groups
+    assert _native.load().pixpro_bn_relu_bits_bytes(N // groups * H * W, C) == N // groups * H * W * C // 8
+    assert _native.load().pixpro_bn_relu_bits_bytes(100, 64) == 0          # no record for this shape: callers keep y
+    g = torch.Generator().manual_seed(sum(shape) + groups)
+    x = (torch.randn(N, C, H, W, generator=g) * 1.3 - 0.2).to(dev).contiguous(memory_format=CL)
+    res = torch.randn(N, C, H, W, generator=g).to(dev).contiguous(memory_format=CL)
+    dy = torch.randn(N, C, H, W, generator=g).to(dev).contiguous(memory_format=CL)
+    out = {}
+    real = _native.call
+    for bits in (True, False):
+        monkeypatch.setattr(sync_bn, "_RELU_BITS", bits)
+        calls = []
+        monkeypatch.setattr(_native, "call", lambda name, *a: (calls.append(name), real(name, *a))[1])
+        bn = FusedSyncBatchNorm(C).to(dev).train()
+        xf, rf = x.clone().requires_grad_(True), res.clone().requires_grad_(True)
+        with view_groups(groups):
+            y = bn(xf, rf, True)
+        y.backward(dy)
+        monkeypatch.setattr(_native, "call", real)
+        used = any(n.endswith("_bits") for n in calls)
+        assert used == bits, calls
+        out[bits] = (y.detach(), xf.grad, rf.grad, bn.weight.grad, bn.bias.grad, bn.running_var.clone())
+    for a, b in zip(out[True], out[False]):
+        assert torch.equal(a, b)
+    # and the record is not written when nothing upstream wants a gradient (the key encoder's passes)
+    monkeypatch.setattr(sync_bn, "_RELU_BITS", True)
+    calls = []
+    monkeypatch.setattr(_native, "call", lambda name, *a: (calls.append(name), real(name, *a))[1])
+    with torch.no_grad():
+        FusedSyncBatchNorm(C).to(dev).train()(x, res, True)
+    assert "pixpro_bn_apply_bits" not in calls and "pixpro_bn_apply" in calls
+
+
+@pytest.mark.parametrize("groups", [1, 2])
+def test_shortcut_link_bitwise_on_deterministic_units(dev, groups, monkeypatch):
+    """ResidualLink: the last BatchNorm of a unit hands (dy, ReLU bits) to `fork` / to the shortcut's BatchNorm instead of
+    writing the masked gradient for autograd to add.  Three residual units whose 'convolutions' are deterministic
+    element-wise scalings (identity shortcut, shortcut with its own BatchNorm, identity again): with and without the link
+    every output and gradient is the same bit for bit; a retained graph hands the gradient over again."""
+    from contrast import sync_bn
+    from contrast.sync_bn import FusedSyncBatchNorm, bn_act, fork, residual_link, view_groups
+    C = 256
+    g = torch.Generator().manual_seed(21 + groups)
+    bns = [FusedSyncBatchNorm(C).to(dev).train() for _ in range(7)]
+    ws = [(torch.rand(1, C, 1, 1, generator=g) + 0.5).to(dev).requires_grad_(True) for _ in range(7)]
+    with torch.no_grad():
+        for m in bns:
+            m.weight.copy_(torch.rand(C, generator=g) + 0.5)
+            m.bias.copy_(torch.randn(C, generator=g) * 0.3)
+
+    def unit(x, i, down):
+        link = residual_link(x, bns[i + 1])
+        if down is None:
+            x, identity = fork(x, link) if link is not None else (x, x)
+        else:
+            identity = bn_act(bns[down], x * ws[down], link_in=link)
+        out = bn_act(bns[i], x * ws[i], relu=True)
+        return bn_act(bns[i + 1], out * ws[i + 1], relu=True, residual=identity, link_out=link)
+
+    def net(x):
+        x = unit(x, 0, None)
+        x = unit(x, 2, 6)
+        return unit(x, 4, None)
+
+    x = torch.randn(3 * groups, C, 5, 7, generator=g).to(dev).contiguous(memory_format=CL)
+    dy = torch.randn(3 * groups, C, 5, 7, generator=g).to(dev).contiguous(memory_format=CL)
+    out = {}
+    for lazy in (True, False):
+        monkeypatch.setattr(sync_bn, "_LAZY_SHORTCUT", lazy)
+        for t in ws + [p for m in bns for p in m.parameters()]:
+            t.grad = None
+        xi = x.clone().requires_grad_(True)
+        with view_groups(groups):
+            y = net(xi)
+        y.backward(dy)
+        out[lazy] = ([y.detach(), xi.grad] + [t.grad.clone() for t in ws]
+                     + [p.grad.clone() for m in bns for p in m.parameters()])
+        if lazy:
+            xi2 = x.clone().requires_grad_(True)
+            with view_groups(groups):
+                y2 = net(xi2)
+            y2.backward(dy, retain_graph=True)
+            g1 = xi2.grad.clone()
+            xi2.grad = None
+            y2.backward(dy)
+            assert torch.equal(g1, xi2.grad)
+    for a, b in zip(out[True], out[False]):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("arch,groups", [("resnet50", 1), ("resnet50", 2), ("resnet18", 1)])
+def test_shortcut_gradient_over_the_link_in_the_encoders(dev, arch, groups, monkeypatch):
+    """The same through the real encoders (contrast/resnet.py): nothing is written for the shortcut (no dresidual pointer),
+    identity shortcuts get one masked add each.  MIOpen's split-K convolutions accumulate with atomics - two passes of the
+    same encoder differ in the last bits and ~50 BatchNorms amplify that - so this is a plumbing check against the
+    run-to-run noise of the plain route itself (a lost or doubled shortcut gradient is an O(1) error); the bit-for-bit
+    statement is test_shortcut_link_bitwise_on_deterministic_units."""
+    from contrast import resnet, sync_bn, _native
+    from contrast.sync_bn import FusedSyncBatchNorm, view_groups
+    torch.manual_seed(11)
+    monkeypatch.setattr(torch.backends.cudnn, "deterministic", True)      # (asks MIOpen for deterministic solvers where it has them)
+    net = FusedSyncBatchNorm.convert(getattr(resnet, arch)(head_type="early_return")).to(dev).to(memory_format=CL).train()
+    with torch.no_grad():      # the zero-initialised last gammas would hide the residual branch's BatchNorm gradients
+        for m in net.modules():
+            if isinstance(m, resnet._Residual):
+                (m.bn2 if m.kind == "basic" else m.bn3).weight.fill_(0.25)
+    x = torch.randn(4 * groups, 3, 128, 128, device=dev).contiguous(memory_format=CL)
+    dy = None
+    out = {}
+    real = _native.call
+    for key, lazy in (("lazy", True), ("plain", False), ("plain2", False)):
+        monkeypatch.setattr(sync_bn, "_LAZY_SHORTCUT", lazy)
+        calls = []
+        monkeypatch.setattr(_native, "call", lambda name, *a: (calls.append((name, a)), real(name, *a))[1])
+        net.zero_grad(set_to_none=True)
+        xi = x.clone().requires_grad_(True)
+        with view_groups(groups):
+            y = net(xi)
+        if dy is None:
+            dy = torch.randn_like(y)
+        y.backward(dy)
+        monkeypatch.setattr(_native, "call", real)
+        out[key] = [y.detach(), xi.grad] + [p.grad for p in net.parameters()]
+        adds = [a for n, a in calls if n == "pixpro_bn_masked_add"]
+        dres = [a[13] for n, a in calls if n == "pixpro_bn_backward_apply_bits"]
+        assert len(dres) > 0
+        if lazy:
+            assert all(d is None for d in dres)                 # nothing written for the shortcut
+            assert 0 < len(adds) <= len(dres)                   # identity shortcuts: one masked add per unit and view
+        else:
+            assert not adds and all(d is not None for d in dres)
+
+    def rel_err(a, b):
+        return (a - b).abs().max().item() / max(b.abs().max().item(), 1e-30)
+    names = ["y", "dx"] + [n for n, _ in net.named_parameters()]
+    worst = []
+    for n, l, p1, p2 in zip(names, out["lazy"], out["plain"], out["plain2"]):
+        noise, got = rel_err(p2, p1), rel_err(l, p1)
+        worst.append((got - 4 * noise, n, got, noise))
+        assert got <= 4 * noise + 1e-5, (n, got, noise)
+    # the comparison must say something: on the big tensors the noise is small
+    assert rel_err(out["plain2"][0], out["plain"][0]) < 1e-2 and rel_err(out["plain2"][1], out["plain"][1]) < 5e-2, sorted(worst)[-3:]
