@@ -206,6 +206,12 @@ def parse():
     ap.add_argument("--bn-view-batch", action="store_true",
                     help="both views of an encoder in one pass with per-view BatchNorm statistics: half the SyncBN collectives "
                          "(same statistics); unmeasured on more than one GPU, off by default")
+    ap.add_argument("--wgrad-stream", choices=("on", "off"), default="off",
+                    help="weight gradients of the online encoder's convolutions on a second HIP stream, overlapping the next "
+                         "layers' BatchNorm backward (contrast/wgrad_stream.py).  It wants one use of a weight per pass, so it "
+                         "switches --bn-view-batch on with it; one rank only (DistributedDataParallel copies a gradient into "
+                         "its bucket the moment autograd delivers it).  Measured neutral on MI355X (214.2 against 214.4 ms "
+                         "per step, profiles/NOTES_r04.md): off by default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-configs", action="store_true",
                     help="skip the two short legs for BASELINE configs[3] (nframe=6, N=64) and configs[4] (448^2, N=64) that the "
@@ -249,6 +255,10 @@ def model_args(a, world):
         argv.append("--lazy-flow")
     if a.fused_bn:
         argv.append("--fused-bn")
+    a.wgrad_stream = a.wgrad_stream == "on" and a.fused_bn and world == 1
+    if a.wgrad_stream:
+        a.bn_view_batch = True
+        argv.append("--wgrad-stream")
     if a.bn_view_batch:
         argv.append("--bn-view-batch")
     # auto = on with ONE rank only.  With several ranks the key branch on a second stream is pointless without --key-bn-group
@@ -850,6 +860,8 @@ def main():
     if rank == 0 and world == 1:
         inner = model.module if hasattr(model, "module") else model
         saved_overlap, inner.overlap_momentum = inner.overlap_momentum, False
+        from contrast import wgrad_stream
+        wgrad_stream.set_enabled(False)           # (the audit step: every kernel on the one stream)
         clock.reset()
         audit = BnAudit() if a.fused_bn else None
         if audit:
@@ -868,6 +880,7 @@ def main():
             args.lazy_flow = False
             ms_lazy = clock.mean_ms()
         inner.overlap_momentum = saved_overlap
+        wgrad_stream.set_enabled(True)
         note(rank, f"single-stream audit step (ms): {ms_single}; lazy-flow step (ms): {ms_lazy}")
 
     extra = None
@@ -899,6 +912,8 @@ def main():
                                    f"p=2, transform_layer=1, LARS, fp32",
                        "batch_norm": ("fused HIP SyncBN+ReLU" + (", two views per pass" if a.bn_view_batch else ""))
                                      if a.fused_bn else "torch (Sync)BatchNorm",
+                       "weight_gradients": ("second HIP stream, both views per encoder pass (contrast/wgrad_stream.py)"
+                                            if a.wgrad_stream else "backward stream"),
                        "key_branch": ("second HIP stream" + (", own SyncBN process group" if a.key_bn_group and world > 1 else ""))
                                      if a.overlap_momentum else "same stream",
                        "miopen": f"immediate mode; {miopen_note}",

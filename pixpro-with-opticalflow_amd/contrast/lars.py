@@ -64,8 +64,11 @@ class LARS(torch.optim.Optimizer):
             self.state[p]['momentum_buffer'] = b
         del lr0
 
-    def zero_grad(self, set_to_none=False):
-        # keep gradient storage alive so the pointer table stays valid
+    def zero_grad(self, set_to_none=True):
+        # None instead of zeros (torch's own default since 2.0; the reference's torch 1.8 zeroes - same gradients either
+        # way): 161 fill launches and 161 accumulate-into-zeros adds per ResNet-50 step disappear, autograd hands its
+        # gradient tensors over as they are.  They may sit at new addresses: the fused step's pointer table follows
+        # (multi_tensor._Table, an asynchronous 5-KB upload when a pointer moved).
         super().zero_grad(set_to_none=set_to_none)
 
     @torch.no_grad()

@@ -23,7 +23,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch.distributed import get_world_size, is_initialized
 
-from .. import ops
+from .. import ops, wgrad_stream
 from ..multi_tensor import ema_update
 from ..sync_bn import FusedSyncBatchNorm, bn_act, view_groups
 from .base import BaseModel
@@ -140,6 +140,12 @@ class PixPro(BaseModel):
                 self._convert_bn(m, self.key_bn_group)
 
         world = get_world_size() if is_initialized() else 1
+        # weight gradients of the online encoder's convolutions on a second stream (contrast/wgrad_stream.py): one rank only -
+        # DistributedDataParallel copies a gradient into its bucket the moment autograd delivers it
+        self.wgrad_stream = bool(getattr(args, "wgrad_stream", False)) and world == 1
+        if self.wgrad_stream:
+            wgrad_stream.convert(self.encoder)
+            wgrad_stream.convert(self.projector)
         self._steps_per_epoch = args.num_instances * 1. / world / args.batch_size
         self.K = int(self._steps_per_epoch * args.epochs)           # PixPro.py:294
         self.k = self.steps_before_epoch(args.start_epoch)          # PixPro.py:295

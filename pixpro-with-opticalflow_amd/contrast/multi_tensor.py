@@ -11,7 +11,9 @@ MAX_TENSORS = 2048     # per C call (include/pixpro_hip.h)
 
 
 class _Table:
-    """Device arrays of pointers / sizes for a list of tensors; rebuilt only when a pointer moves."""
+    """Device arrays of pointers / sizes for a list of tensors; rebuilt only when a pointer moves.  A rebuild is an
+    asynchronous copy from pinned memory on the current stream (gradients that autograd allocates anew every step may move:
+    the step must not wait for the device because of it); the table in use by an earlier launch is a different tensor."""
 
     def __init__(self):
         self.key = None
@@ -23,7 +25,9 @@ class _Table:
             n = len(groups[0])
             host = torch.tensor([[t.data_ptr() for t in g] for g in groups] + [[t.numel() for t in groups[0]]],
                                 dtype=torch.int64)
-            self.dev = host.to(device)
+            if torch.device(device).type == "cuda":
+                host = host.pin_memory()
+            self.dev = host.to(device, non_blocking=True)
             self.key = key
             self.n = n
         return self.dev

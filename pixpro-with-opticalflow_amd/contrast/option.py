@@ -95,6 +95,9 @@ _FLAGS = [
     (("--bn-view-batch",), dict(action="store_true", help="run both views through an encoder in ONE pass with per-view "
                                                           "BatchNorm statistics (needs --fused-bn): same statistics, half "
                                                           "the SyncBN collectives per step")),
+    (("--wgrad-stream",), dict(action="store_true", help="weight gradients of the encoder convolutions on a second HIP "
+                                                         "stream, overlapping the next layers' BatchNorm backward "
+                                                         "(contrast/wgrad_stream.py; one rank, use with --bn-view-batch)")),
 ]
 
 

@@ -23,7 +23,7 @@ import torch
 import torch.distributed as dist
 from torch.nn.parallel import DistributedDataParallel
 
-from contrast import models, resnet, util
+from contrast import models, resnet, util, wgrad_stream
 from contrast.lars import LARS, add_weight_decay
 from contrast.lr_scheduler import get_scheduler
 from contrast.option import parse_option
@@ -139,6 +139,7 @@ def train_step(model, optimizer, scheduler, data, args, flow_model=None):
     loss, pos_num_list = model(data[0], data[1], coord1, coord2)
     optimizer.zero_grad()
     loss.backward()
+    wgrad_stream.join()          # weight gradients computed on the side stream (--wgrad-stream); nothing to wait for otherwise
     optimizer.step()
     scheduler.step()
     return loss, pos_num_list, info
