@@ -46,7 +46,7 @@ struct BnCaps { int stats, apply, bwd_reduce, bwd_apply; };
 // PIXPRO_BN_CAPS="stats,apply,bwd_reduce,bwd_apply" overrides the defaults (tuning knob, tools/bn_sweep.py)
 inline BnCaps bn_caps() {
   static const BnCaps caps = [] {
-    BnCaps c{256, 512, 1024, 512};
+    BnCaps c{384, 512, 1024, 512};
     if (const char* e = getenv("PIXPRO_BN_CAPS")) {
       int a, b, d, f;
       if (sscanf(e, "%d,%d,%d,%d", &a, &b, &d, &f) == 4) {
@@ -81,6 +81,35 @@ inline BnTile bn_tile(int64_t M, int C4, int cap) {
 
 __device__ __forceinline__ float4 ld4(const float* p, int64_t i4) { return reinterpret_cast<const float4*>(p)[i4]; }
 __device__ __forceinline__ void st4(float* p, int64_t i4, float4 v) { reinterpret_cast<float4*>(p)[i4] = v; }
+// streaming (non-temporal) forms for tensors that are swept once: global_load_dwordx4 / global_store_dwordx4 ... nt
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld4nt(const float* p, int64_t i4) {
+  const v4f_t v = __builtin_nontemporal_load(reinterpret_cast<const v4f_t*>(p) + i4);
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void st4nt(float* p, int64_t i4, float4 v) {
+  v4f_t w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w;
+  __builtin_nontemporal_store(w, reinterpret_cast<v4f_t*>(p) + i4);
+}
+// NT (template flag of the sweeping kernels): the activation loads use the streaming form.  Measured per ResNet-50 shape at
+// N = 256 (tools/bn_shapes.py, profiles/r04_bn_nontemporal.txt): the read-only sweeps gain 25 % on tensors the Infinity Cache
+// cannot hold (statistics of an 822 MB tensor 170 -> 123 us, 6.7 TB/s), the element-wise kernels must then stream too (a
+// streaming statistics pass leaves nothing cached for them); tensors of <= 51 MB lose (they live in the 256 MB Infinity
+// Cache between the convolution that wrote them and these kernels).  Stores stay plain: the next convolution reads them.
+#define LDX(NT, p, i) ((NT) ? ld4nt(p, i) : ld4(p, i))
+struct BnStream { bool stats, apply, bwd_reduce, bwd_apply; };
+inline BnStream bn_stream_policy(int64_t M, int C, bool writes_dres) {
+  static const int mode = [] { const char* e = getenv("PIXPRO_BN_STREAM"); return e ? atoi(e) : -1; }();   // 0 / 1 force, tests
+  if (mode == 0) return BnStream{false, false, false, false};
+  if (mode == 1) return BnStream{true, true, true, true};
+  const double mb = (double)M * C * 4 / 1e6;
+  BnStream p;
+  p.stats = p.apply = mb >= 80.0;
+  p.bwd_reduce = mb >= 150.0;
+  // the input-gradient kernel: streaming loads pay up to ~600 MB and wherever a second tensor is written (measured)
+  p.bwd_apply = mb >= 150.0 && (mb < 600.0 || writes_dres);
+  return p;
+}
 
 // Row walk of a work-group: the four rows a thread has in flight are gridDim.y * TY rows apart.  (Four ADJACENT row blocks
 // per thread - 16 KB contiguous per work-group and iteration at C = 256 - measure the same: 57.6 against 58.0 ms of
@@ -179,13 +208,14 @@ __device__ __forceinline__ bool last_block_fold(int* __restrict__ tickets, const
 
 // partial[by][0][C] = sum (x - K), partial[by][1][C] = sum (x - K)^2,  K = x[0][c]; the last work-group of a chunk:
 // packed[0..C) = mean, packed[C..2C) = biased variance, packed[2C] = M     (what one rank contributes)
+template <bool NT>
 __global__ void __launch_bounds__(BN_TPB)
 k_stats(const float* __restrict__ x, int* __restrict__ tickets, float* __restrict__ partial, float* __restrict__ packed,
         int64_t M, int C4, int TX, int TY) {
   __shared__ float4 sh[2 * BN_TPB];
   float4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
   const float4 K = ld4(x, blockIdx.x * TX + (threadIdx.x & (TX - 1)));
-#define BODY(row) { const float4 v = ld4(x, (row) * C4 + c4);                                                  \
+#define BODY(row) { const float4 v = LDX(NT, x, (row) * C4 + c4);                                                 \
     const float dx_ = v.x - K.x, dy_ = v.y - K.y, dz_ = v.z - K.z, dw_ = v.w - K.w;                            \
     s.x += dx_; s.y += dy_; s.z += dz_; s.w += dw_;                                                           \
     q.x = __builtin_fmaf(dx_, dx_, q.x); q.y = __builtin_fmaf(dy_, dy_, q.y);                                  \
@@ -314,7 +344,7 @@ __device__ __forceinline__ BnMerged merge_channel(const float* __restrict__ gath
 // BITS (needs TX == 64 and C4 % 64 == 0, so that a wave holds the 64 consecutive float4 i0 .. i0 + 63 of one row, i0 % 64 == 0):
 // the ReLU decisions of those 256 elements leave as one 32-byte record, bits[(i0 / 64) * 4 + k] bit l = component k of
 // float4 i0 + l is positive.  v_cmp produces the four words as they are; lanes 0..3 store them.
-template <bool RELU, bool RES, bool BITS>
+template <bool RELU, bool RES, bool BITS, bool NT>
 __global__ void __launch_bounds__(BN_TPB)
 k_apply(const float* __restrict__ gathered, int W, const float* __restrict__ weight, const float* __restrict__ bias,
         float* __restrict__ running_mean, float* __restrict__ running_var, float momentum, float eps,
@@ -340,10 +370,10 @@ k_apply(const float* __restrict__ gathered, int W, const float* __restrict__ wei
     }
   }
   const float4 sc = make_float4(scv[0], scv[1], scv[2], scv[3]), sf = make_float4(sfv[0], sfv[1], sfv[2], sfv[3]);
-#define BODY(row) { const int64_t i = (row) * C4 + c4; const float4 v = ld4(x, i); float4 o;                   \
+#define BODY(row) { const int64_t i = (row) * C4 + c4; const float4 v = LDX(NT, x, i); float4 o;                 \
     o.x = __builtin_fmaf(v.x, sc.x, sf.x); o.y = __builtin_fmaf(v.y, sc.y, sf.y);                              \
     o.z = __builtin_fmaf(v.z, sc.z, sf.z); o.w = __builtin_fmaf(v.w, sc.w, sf.w);                              \
-    if (RES) { const float4 e = ld4(res, i); o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w; }                 \
+    if (RES) { const float4 e = LDX(NT, res, i); o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w; }                 \
     if (RELU) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }  \
     st4(y, i, o);                                                                                             \
     if (BITS) { const unsigned long long b0 = __ballot(o.x > 0.f), b1 = __ballot(o.y > 0.f),                   \
@@ -376,7 +406,7 @@ k_apply(const float* __restrict__ gathered, int W, const float* __restrict__ wei
                      g.w = (((hi_ ? q##k.w : q##k.z) >> sh_) & 1u) ? g.w : 0.f; }
 
 // partial[by][0][C] = sum dz, partial[by][1][C] = sum dz * (x - mean);  dz = dy masked by the forward's ReLU decision
-template <int MODE>
+template <int MODE, bool NT>
 __global__ void __launch_bounds__(BN_TPB)
 k_bwd_reduce(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ y,
              const float* __restrict__ scale_shift, const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -388,7 +418,7 @@ k_bwd_reduce(const float* __restrict__ dy, const float* __restrict__ x, const fl
   const float4 mu = ld4(mean, cc);
   float4 sc = mu, sf = mu;
   if (MODE == 2) { sc = ld4(scale_shift, cc); sf = ld4(scale_shift + (int64_t)C4 * 4, cc); }
-#define LOAD(k, row) const int64_t i##k = (row) * C4 + c4; float4 g##k = ld4(dy, i##k); const float4 v##k = ld4(x, i##k); \
+#define LOAD(k, row) const int64_t i##k = (row) * C4 + c4; float4 g##k = LDX(NT, dy, i##k); const float4 v##k = LDX(NT, x, i##k); \
     BN_MASK_LOAD(MODE, k, i##k)
 #define USE(k, row) { BN_MASK_APPLY(MODE, k, g##k, v##k)                                                        \
     s.x += g##k.x; s.y += g##k.y; s.z += g##k.z; s.w += g##k.w;                                                \
@@ -421,7 +451,7 @@ k_bwd_reduce(const float* __restrict__ dy, const float* __restrict__ x, const fl
 }
 
 // dx = (dz - sum_dz/n - (x - mean) * invstd^2 * sum_dz_xmu/n) * invstd * w        (batch_norm_backward_elemt)
-template <int MODE, bool RES>
+template <int MODE, bool RES, bool NT>
 __global__ void __launch_bounds__(BN_TPB)
 k_bwd_apply(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ y,
             const float* __restrict__ scale_shift, const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -446,7 +476,7 @@ k_bwd_apply(const float* __restrict__ dy, const float* __restrict__ x, const flo
   b.x = -(sx.x * inv_n) * is.x * is.x * a.x; b.y = -(sx.y * inv_n) * is.y * is.y * a.y;
   b.z = -(sx.z * inv_n) * is.z * is.z * a.z; b.w = -(sx.w * inv_n) * is.w * is.w * a.w;
   c.x = -(sd.x * inv_n) * a.x; c.y = -(sd.y * inv_n) * a.y; c.z = -(sd.z * inv_n) * a.z; c.w = -(sd.w * inv_n) * a.w;
-#define LOAD(k, row) const int64_t i##k = (row) * C4 + c4; float4 g##k = ld4(dy, i##k); const float4 v##k = ld4(x, i##k); \
+#define LOAD(k, row) const int64_t i##k = (row) * C4 + c4; float4 g##k = LDX(NT, dy, i##k); const float4 v##k = LDX(NT, x, i##k); \
     BN_MASK_LOAD(MODE, k, i##k)
 #define USE(k, row) { BN_MASK_APPLY(MODE, k, g##k, v##k)                                                        \
     if (RES) st4(dres, i##k, g##k);                                                                           \
@@ -465,6 +495,7 @@ k_bwd_apply(const float* __restrict__ dy, const float* __restrict__ x, const flo
 // convolution branch's and of what the unit's last BatchNorm passes to the shortcut, dz = dy masked by the ReLU decisions:
 // with the bit record that term need not be written by k_bwd_apply and read back by an add - this kernel reads dy and the
 // bits instead (one pass over the widest tensors less per unit).  A wave holds 64 consecutive float4, i0 % 64 == 0.
+template <bool NT>
 __global__ void __launch_bounds__(BN_TPB)
 k_masked_add(const float* __restrict__ a, const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ out,
              int64_t n4) {
@@ -472,8 +503,8 @@ k_masked_add(const float* __restrict__ a, const float* __restrict__ dy, const fl
   const float4 sc = {0.f, 0.f, 0.f, 0.f}, sf = sc;       // (named by the other modes of BN_MASK_APPLY)
   const int64_t step = (int64_t)gridDim.x * BN_TPB, jump = 4 * step;
   int64_t i = (int64_t)blockIdx.x * BN_TPB + threadIdx.x;
-#define LOAD(k, idx) const int64_t i##k = (idx); float4 g##k = ld4(dy, i##k); float4 e##k = {0.f, 0.f, 0.f, 0.f};   \
-    if (a) e##k = ld4(a, i##k);                                                                               \
+#define LOAD(k, idx) const int64_t i##k = (idx); float4 g##k = LDX(NT, dy, i##k); float4 e##k = {0.f, 0.f, 0.f, 0.f};   \
+    if (a) e##k = LDX(NT, a, i##k);                                                                               \
     BN_MASK_LOAD(3, k, i##k)
 #define USE(k, idx) { BN_MASK_APPLY(3, k, g##k, g##k)                                                           \
     g##k.x += e##k.x; g##k.y += e##k.y; g##k.z += e##k.z; g##k.w += e##k.w;                                    \
@@ -505,8 +536,12 @@ size_t bn_workspace_floats(int64_t M, int C) {
 int run_bn_stats(const float* x, int64_t M, int C, float* ws, float* packed, hipStream_t st) {
   const BnTile t = bn_tile(M, C / 4, bn_caps().stats);
   const bool fold = bn_fold_in_kernel();
-  hipLaunchKernelGGL(k_stats, dim3(t.gx, t.gy), dim3(BN_TPB), 0, st, x, fold ? reinterpret_cast<int*>(ws) : nullptr, ws + BN_HDR,
-                     packed, M, C / 4, t.TX, t.TY);
+  if (bn_stream_policy(M, C, false).stats)
+    hipLaunchKernelGGL(k_stats<true>, dim3(t.gx, t.gy), dim3(BN_TPB), 0, st, x, fold ? reinterpret_cast<int*>(ws) : nullptr,
+                       ws + BN_HDR, packed, M, C / 4, t.TX, t.TY);
+  else
+    hipLaunchKernelGGL(k_stats<false>, dim3(t.gx, t.gy), dim3(BN_TPB), 0, st, x, fold ? reinterpret_cast<int*>(ws) : nullptr,
+                       ws + BN_HDR, packed, M, C / 4, t.TX, t.TY);
   CHECKED("k_stats");
   if (!fold) {
     hipLaunchKernelGGL(k_stats_finalize, dim3((C + FIN_CH - 1) / FIN_CH), dim3(BN_TPB), 0, st, x, ws + BN_HDR, t.gy, M, C, packed);
@@ -527,8 +562,11 @@ int run_bn_apply(const float* gathered, int W, const float* x, const float* res,
   const BnTile t = bn_tile(M, C / 4, bn_caps().apply);
   const dim3 g(t.gx, t.gy), b(BN_TPB);
   unsigned long long* bits = static_cast<unsigned long long*>(relu_bits);
-#define APPLY(R, S, B) hipLaunchKernelGGL((k_apply<R, S, B>), g, b, 0, st, gathered, W, weight, bias, running_mean, running_var, \
-                                          momentum, eps, mean, invstd, scale_shift, x, res, y, bits, M, C / 4, t.TX, t.TY)
+  const bool nt = bn_stream_policy(M, C, false).apply;
+#define APPLY_(R, S, B, N) hipLaunchKernelGGL((k_apply<R, S, B, N>), g, b, 0, st, gathered, W, weight, bias, running_mean,    \
+                                              running_var, momentum, eps, mean, invstd, scale_shift, x, res, y, bits, M,     \
+                                              C / 4, t.TX, t.TY)
+#define APPLY(R, S, B) do { if (nt) APPLY_(R, S, B, true); else APPLY_(R, S, B, false); } while (0)
   if (bits) {
     if (!relu || t.TX != 64 || !bn_relu_bits_bytes(M, C)) return PIXPRO_ERR_ARG;
     if (res) APPLY(true, true, true); else APPLY(true, false, true);
@@ -538,6 +576,7 @@ int run_bn_apply(const float* gathered, int W, const float* x, const float* res,
   else if (res) APPLY(false, true, false);
   else APPLY(false, false, false);
 #undef APPLY
+#undef APPLY_
   CHECKED("k_apply");
   return PIXPRO_OK;
 }
@@ -557,9 +596,11 @@ int run_bn_bwd_reduce(const float* dy, const float* x, const float* y, const flo
   }
   const dim3 g(t.gx, t.gy), b(BN_TPB);
   const bool fold = bn_fold_in_kernel();
-#define REDUCE(MD) hipLaunchKernelGGL((k_bwd_reduce<MD>), g, b, 0, st, dy, x, y, scale_shift, mean, invstd,                \
-                                     fold ? reinterpret_cast<int*>(ws) : nullptr, ws + BN_HDR, sums, grad_weight, grad_bias, M, \
-                                     C / 4, t.TX, t.TY)
+  const bool nt = bn_stream_policy(M, C, false).bwd_reduce;
+#define REDUCE_(MD, N) hipLaunchKernelGGL((k_bwd_reduce<MD, N>), g, b, 0, st, dy, x, y, scale_shift, mean, invstd,             \
+                                          fold ? reinterpret_cast<int*>(ws) : nullptr, ws + BN_HDR, sums, grad_weight,       \
+                                          grad_bias, M, C / 4, t.TX, t.TY)
+#define REDUCE(MD) do { if (nt) REDUCE_(MD, true); else REDUCE_(MD, false); } while (0)
   switch (mask_mode(relu, scale_shift, relu_bits)) {
     case 0: REDUCE(0); break;
     case 1: REDUCE(1); break;
@@ -567,6 +608,7 @@ int run_bn_bwd_reduce(const float* dy, const float* x, const float* y, const flo
     default: REDUCE(3); break;
   }
 #undef REDUCE
+#undef REDUCE_
   CHECKED("k_bwd_reduce");
   if (!fold) {
     hipLaunchKernelGGL(k_bwd_finalize, dim3((C + FIN_CH - 1) / FIN_CH), dim3(BN_TPB), 0, st, ws + BN_HDR, t.gy, C, invstd, sums,
@@ -585,12 +627,15 @@ int run_bn_bwd_apply(const float* dy, const float* x, const float* y, const floa
     y = static_cast<const float*>(relu_bits);
   }
   const dim3 g(t.gx, t.gy), b(BN_TPB);
-#define BAPPLY(MD, S) hipLaunchKernelGGL((k_bwd_apply<MD, S>), g, b, 0, st, dy, x, y, scale_shift, mean, invstd, weight, \
-                                         sums, counts, world, count_stride, dx, dres, M, C / 4, t.TX, t.TY)
+  const bool nt = bn_stream_policy(M, C, dres != nullptr).bwd_apply;
+#define BAPPLY_(MD, S, N) hipLaunchKernelGGL((k_bwd_apply<MD, S, N>), g, b, 0, st, dy, x, y, scale_shift, mean, invstd, weight, \
+                                             sums, counts, world, count_stride, dx, dres, M, C / 4, t.TX, t.TY)
+#define BAPPLY(MD, S) do { if (nt) BAPPLY_(MD, S, true); else BAPPLY_(MD, S, false); } while (0)
   const int mode = mask_mode(relu, scale_shift, relu_bits);
   if (dres) { if (mode == 0) BAPPLY(0, true); else if (mode == 1) BAPPLY(1, true); else if (mode == 2) BAPPLY(2, true); else BAPPLY(3, true); }
   else { if (mode == 0) BAPPLY(0, false); else if (mode == 1) BAPPLY(1, false); else if (mode == 2) BAPPLY(2, false); else BAPPLY(3, false); }
 #undef BAPPLY
+#undef BAPPLY_
   CHECKED("k_bwd_apply");
   return PIXPRO_OK;
 }
@@ -599,8 +644,12 @@ int run_bn_masked_add(const float* a, const float* dy, const void* relu_bits, fl
   if (!bn_relu_bits_bytes(M, C)) return PIXPRO_ERR_ARG;
   const int64_t n4 = M * (int64_t)(C / 4);
   const int64_t blocks = std::min<int64_t>((n4 + (int64_t)BN_TPB * 4 - 1) / ((int64_t)BN_TPB * 4), 2048);
-  hipLaunchKernelGGL(k_masked_add, dim3((unsigned)std::max<int64_t>(blocks, 1)), dim3(BN_TPB), 0, st, a, dy,
-                     static_cast<const float*>(relu_bits), out, n4);
+  if (bn_stream_policy(M, C, true).bwd_apply)
+    hipLaunchKernelGGL(k_masked_add<true>, dim3((unsigned)std::max<int64_t>(blocks, 1)), dim3(BN_TPB), 0, st, a, dy,
+                       static_cast<const float*>(relu_bits), out, n4);
+  else
+    hipLaunchKernelGGL(k_masked_add<false>, dim3((unsigned)std::max<int64_t>(blocks, 1)), dim3(BN_TPB), 0, st, a, dy,
+                       static_cast<const float*>(relu_bits), out, n4);
   CHECKED("k_masked_add");
   return PIXPRO_OK;
 }

@@ -34,8 +34,9 @@ print(f"{'C':>5} {'H':>4} {'res':>3} {'MB':>7} | " + " | ".join(f"{k:>22}" for k
 for C, H, cnt, nres in SHAPES:
     x = torch.randn(N, C, H, H, device="cuda").contiguous(memory_format=torch.channels_last)
     bn = FusedSyncBatchNorm(C).cuda().train()
-    for res in ([False, True] if nres else [False]):
-        r = torch.randn_like(x).requires_grad_(True) if res else None
+    # res = 2: the residual wants no gradient tensor - what the step runs behind a ResidualLink (k_bwd_apply<3, false>)
+    for res in ([0, 1, 2] if nres else [0]):
+        r = (torch.randn_like(x).requires_grad_(res == 1)) if res else None
         xg = x.clone().requires_grad_(True)
         rec.clear()
         for _ in range(7):
@@ -43,12 +44,14 @@ for C, H, cnt, nres in SHAPES:
             y.backward(torch.ones_like(y))
         torch.cuda.synchronize()
         mb = x.numel() * 4 / 1e6
-        passes = {"stats": 1, "apply": 2 + res, "backward_reduce": 2 + (res and not C % 256 == 0), "backward_apply": 3 + res}
+        passes = {"stats": 1, "apply": 2 + bool(res), "backward_reduce": 2 + (bool(res) and not C % 256 == 0),
+                  "backward_apply": 3 + (res == 1)}
         cells = []
         for k in ("stats", "apply", "backward_reduce", "backward_apply"):
             ms = statistics.median(s.elapsed_time(e) for s, e in rec[k])
             cells.append(f"{ms * 1e3:8.1f} us {passes[k] * mb / ms / 1e3:6.2f} TB/s")
             n = (nres if res else cnt - nres) * (4 if k in ("stats", "apply") else 2)
-            tot[k] = tot.get(k, 0.0) + ms * n
+            if res != 1:                          # the per-step total counts the linked form of the residual layers
+                tot[k] = tot.get(k, 0.0) + ms * n
         print(f"{C:>5} {H:>4} {int(res):>3} {mb:7.1f} | " + " | ".join(cells), flush=True)
 print("per step (4 forward + 2 backward passes), ms:", {k: round(v, 2) for k, v in tot.items()}, "sum", round(sum(tot.values()), 2))
