@@ -45,6 +45,8 @@ def run(a):
     dev = "cuda"
     out = {}
     for key, count in problems(a.arch, a.image_size).items():
+        if a.only and "x".join(map(str, key)) not in a.only:
+            continue
         cin, h, w, cout, k, stride, pad, dil, groups = key
         x = torch.randn(a.batch, cin, h, w, device=dev).contiguous(memory_format=torch.channels_last)
         wt = torch.randn(cout, cin // groups, k, k, device=dev).contiguous(memory_format=torch.channels_last)
@@ -104,6 +106,7 @@ if __name__ == "__main__":
     ap.add_argument("--tag", default="default")
     ap.add_argument("--out", default=None)
     ap.add_argument("--compare", nargs=2)
+    ap.add_argument("--only", nargs="*", default=None, help="problem keys (as printed) to time")
     a = ap.parse_args()
     if a.compare:
         compare(*a.compare)
