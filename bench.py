@@ -317,6 +317,10 @@ class BnAudit:
         "pixpro_bn_backward_reduce_bits": (5, 6, lambda a: 2 + 1 / 32),
         "pixpro_bn_backward_apply_bits": (10, 11, lambda a: 3 + 1 / 32 + (a[13] is not None)),
         "pixpro_bn_masked_add": (4, 5, lambda a: 2 + (a[0] is not None) + 1 / 32),
+        # the stem in one pass (rows = N H W of the full-resolution tensor; the pooled tensors are a quarter of it)
+        "pixpro_bn_apply_pool": (lambda a: a[9] * a[10] * a[11], 12, lambda a: 1.25),
+        "pixpro_bn_pool_backward_reduce": (lambda a: a[5] * a[6] * a[7], 8, lambda a: 1.25),
+        "pixpro_bn_pool_backward_apply": (lambda a: a[10] * a[11] * a[12], 13, lambda a: 2.25),
     }
 
     def __init__(self):
@@ -333,7 +337,8 @@ class BnAudit:
             s.record()
             self.inner(name, *a)
             e.record()
-            self.rec.append((name, s, e, a[spec[0]] * a[spec[1]] * 4 * spec[2](a)))
+            rows = spec[0](a) if callable(spec[0]) else a[spec[0]]
+            self.rec.append((name, s, e, rows * a[spec[1]] * 4 * spec[2](a)))
         native.call = call
 
     def remove(self):
@@ -342,7 +347,8 @@ class BnAudit:
     def summary(self):
         out = {}
         for name, s, e, nbytes in self.rec:
-            o = out.setdefault(name.replace("pixpro_", "").replace("_bits", ""), [0, 0.0, 0])
+            short = name.replace("pixpro_", "").replace("_bits", "").replace("bn_pool_backward", "bn_backward").replace("apply_pool", "apply")
+            o = out.setdefault(short, [0, 0.0, 0])
             o[0] += 1
             o[1] += s.elapsed_time(e)
             o[2] += nbytes

@@ -278,6 +278,27 @@ int pixpro_bn_backward_apply_bits(const float* dy, const float* x, const void* r
 int pixpro_bn_masked_add(const float* a, const float* dy, const void* relu_bits, float* out, int64_t rows,
                          int32_t C, void* stream);
 
+/* ---- the stem: BatchNorm + ReLU + 3x3 / stride 2 / pad 1 max pooling in one pass (1.2) ----
+ * contrast/resnet.py: `x = maxpool(relu(bn1(conv1(x))))`.  The normalised full-resolution tensor is never written: the
+ * forward reads x [N,H,W,C] (after pixpro_bn_stats + the collective, as for pixpro_bn_apply) and writes the pooled
+ * tensor [N,(H-1)/2+1,(W-1)/2+1,C]; the backward calls take the POOLED gradient, rebuild which position won each window
+ * (first maximum in row-major window order, as ATen's indices; windows summed in ascending order, as ATen's backward)
+ * and continue as pixpro_bn_backward_reduce / pixpro_bn_backward_apply do.  C % 32 == 0.
+ * Workspace as for pixpro_bn_backward_reduce with rows = N*H*W. */
+int pixpro_bn_pool_supported(int32_t N, int32_t H, int32_t W, int32_t C);
+int pixpro_bn_apply_pool(const float* gathered, int32_t world, const float* x, const float* weight, const float* bias,
+                         float* running_mean, float* running_var, float momentum, float eps, int32_t N, int32_t H,
+                         int32_t W, int32_t C, float* pooled, float* mean, float* invstd, float* scale_shift,
+                         void* stream);
+int pixpro_bn_pool_backward_reduce(const float* dpooled, const float* x, const float* scale_shift, const float* mean,
+                                   const float* invstd, int32_t N, int32_t H, int32_t W, int32_t C, void* workspace,
+                                   size_t workspace_bytes, float* sums, float* grad_weight, float* grad_bias,
+                                   void* stream);
+int pixpro_bn_pool_backward_apply(const float* dpooled, const float* x, const float* scale_shift, const float* mean,
+                                  const float* invstd, const float* weight, const float* sums, const float* counts,
+                                  int32_t world, int64_t count_stride, int32_t N, int32_t H, int32_t W, int32_t C,
+                                  float* dx, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

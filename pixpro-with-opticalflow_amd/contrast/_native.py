@@ -80,6 +80,13 @@ SIGNATURES = {
     "pixpro_bn_backward_apply_bits": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i64, _i32,
                                                      _vp, _vp, _vp]),
     "pixpro_bn_masked_add": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _vp]),
+    "pixpro_bn_pool_supported": (ctypes.c_int, [_i32, _i32, _i32, _i32]),
+    "pixpro_bn_apply_pool": (ctypes.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _i32, _i32, _i32, _i32,
+                                            _vp, _vp, _vp, _vp, _vp]),
+    "pixpro_bn_pool_backward_reduce": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _sz, _vp, _vp, _vp,
+                                                      _vp]),
+    "pixpro_bn_pool_backward_apply": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _i32, _i32,
+                                                     _vp, _vp]),
 }
 
 _lib = None

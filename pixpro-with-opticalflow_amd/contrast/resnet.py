@@ -10,7 +10,7 @@ import math
 
 import torch.nn as nn
 
-from .sync_bn import bn_act, fork, residual_link
+from .sync_bn import bn_act, bn_relu_pool, fork, residual_link
 
 ARCHS = {
     # name: (block, depths, extra kwargs)
@@ -143,7 +143,7 @@ class ResNet(nn.Module):
                 nn.init.zeros_((m.bn2 if m.kind == "basic" else m.bn3).weight)
 
     def forward(self, x):
-        x = self.maxpool(bn_act(self.bn1, self.conv1(x), relu=True))
+        x = bn_relu_pool(self.bn1, self.conv1(x), self.maxpool)      # one fused pass with FusedSyncBatchNorm
         c2 = self.layer1(x)
         c3 = self.layer2(c2)
         c4 = self.layer3(c3)

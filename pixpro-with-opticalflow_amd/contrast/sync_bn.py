@@ -289,6 +289,94 @@ class _FusedBN(torch.autograd.Function):
         return dx, gw, gb, dres, None, None, None, None, None, None, None, None, None, None
 
 
+# PIXPRO_BN_FUSED_POOL=0: the stem as BatchNorm + ReLU, then ATen's max pooling (A/B switch, tests)
+_FUSED_POOL = os.environ.get("PIXPRO_BN_FUSED_POOL", "1") != "0"
+
+
+class _FusedBNPool(torch.autograd.Function):
+    """maxpool3x3/2/1(relu(batch_norm(x))) of the ResNet stem without the full-resolution tensor in between
+    (csrc/sync_bn.hip: k_apply_pool, k_pool_bwd_reduce, k_pool_bwd_apply).  Statistics, collectives and the per-view
+    treatment are those of _FusedBN."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, group, G):
+        x, rows, C = _rows_view(x, "input")
+        N, _, H, W = x.shape
+        if N % G:
+            raise RuntimeError(f"view_groups({G}): batch {N} is not a multiple of the number of views")
+        Nv, rows = N // G, rows // G
+        dev = x.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        lib = nv.load()
+        wsb = lib.pixpro_bn_workspace_bytes(rows, C)
+        ws = nv.zeroed_workspace(wsb, dev)
+        small = torch.empty(G * (2 * C + 4) + G * 4 * C, **f32)
+        packed = small[:G * (2 * C + 1)].view(G, 2 * C + 1)
+        for g in range(G):
+            nv.call("pixpro_bn_stats", nv.ptr(_part(x, g, G)), rows, C, nv.ptr(ws), wsb, nv.ptr(packed[g]), nv.stream())
+        world = _world(group)
+        if world > 1:
+            gathered = torch.empty(world, G, 2 * C + 1, **f32)
+            if dist.get_backend(group) == "gloo":
+                parts = list(gathered.unbind(0))
+                dist.all_gather(parts, packed, group=group)
+                gathered = torch.stack(parts)
+            else:
+                dist.all_gather_into_tensor(gathered, packed, group=group)
+            gathered = gathered.transpose(0, 1).contiguous() if G > 1 else gathered.reshape(1, world, 2 * C + 1)
+        else:
+            gathered = packed.reshape(G, 1, 2 * C + 1)
+        PH, PW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        pooled = torch.empty((N, C, PH, PW), **f32).contiguous(memory_format=torch.channels_last)
+        rest = small[G * (2 * C + 4):]
+        mean, invstd, scale_shift = rest[:G * C].view(G, C), rest[G * C:2 * G * C].view(G, C), rest[2 * G * C:].view(G, 2 * C)
+        for g in range(G):
+            nv.call("pixpro_bn_apply_pool", nv.ptr(gathered[g]), world, nv.ptr(_part(x, g, G)), nv.ptr(weight), nv.ptr(bias),
+                    nv.ptr(running_mean), nv.ptr(running_var), float(momentum), float(eps), Nv, H, W, C,
+                    nv.ptr(_part(pooled, g, G)), nv.ptr(mean[g]), nv.ptr(invstd[g]), nv.ptr(scale_shift[g]), nv.stream())
+        ctx.save_for_backward(x, weight, mean, invstd, scale_shift, gathered)
+        ctx.meta = (Nv, H, W, C, rows, group, world, G)
+        return pooled
+
+    @staticmethod
+    def backward(ctx, dp):
+        x, weight, mean, invstd, scale_shift, gathered = ctx.saved_tensors
+        Nv, H, W, C, rows, group, world, G = ctx.meta
+        if not dp.is_contiguous(memory_format=torch.channels_last):
+            dp = dp.contiguous(memory_format=torch.channels_last)
+        dev = x.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        wsb = nv.load().pixpro_bn_workspace_bytes(rows, C)
+        ws = nv.zeroed_workspace(wsb, dev)
+        need_w = weight is not None and ctx.needs_input_grad[1]
+        need_b = ctx.needs_input_grad[2]
+        small = torch.empty(G * 4 * C, **f32)
+        sums = small[:2 * G * C].view(G, 2 * C)
+        gw = small[2 * G * C:3 * G * C].view(G, C) if need_w else None
+        gb = small[3 * G * C:].view(G, C) if need_b else None
+        for g in range(G):
+            nv.call("pixpro_bn_pool_backward_reduce", nv.ptr(_part(dp, g, G)), nv.ptr(_part(x, g, G)), nv.ptr(scale_shift[g]),
+                    nv.ptr(mean[g]), nv.ptr(invstd[g]), Nv, H, W, C, nv.ptr(ws), wsb, nv.ptr(sums[g]),
+                    nv.ptr(gw[g] if need_w else None), nv.ptr(gb[g] if need_b else None), nv.stream())
+        if world > 1:
+            dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            for g in range(G):
+                counts = ctypes.c_void_p(gathered[g].data_ptr() + 2 * C * 4)
+                nv.call("pixpro_bn_pool_backward_apply", nv.ptr(_part(dp, g, G)), nv.ptr(_part(x, g, G)), nv.ptr(scale_shift[g]),
+                        nv.ptr(mean[g]), nv.ptr(invstd[g]), nv.ptr(weight), nv.ptr(sums[g]), counts, world, 2 * C + 1,
+                        Nv, H, W, C, nv.ptr(_part(dx, g, G)), nv.stream())
+        if G > 1:
+            gw = gw.sum(0) if need_w else None
+            gb = gb.sum(0) if need_b else None
+        else:
+            gw = gw[0] if need_w else None
+            gb = gb[0] if need_b else None
+        return dx, gw, gb, None, None, None, None, None, None
+
+
 def _flush_counter_hook(module, prefix, keep_vars):
     module._flush_counter()
 
@@ -357,6 +445,14 @@ class FusedSyncBatchNorm(nn.modules.batchnorm._BatchNorm):
             out = out + residual
         return F.relu(out) if relu else out
 
+    def forward_pool(self, input):
+        """maxpool3x3/2/1(relu(bn(input))) in one pass (training mode; see bn_relu_pool)."""
+        self._check_input_dim(input)
+        if self._buffers.get("num_batches_tracked") is not None:
+            self._nbt_pending += _VIEW_GROUPS
+        return _FusedBNPool.apply(input, self.weight, self.bias, self.running_mean, self.running_var, self.momentum, self.eps,
+                                  self.process_group, _VIEW_GROUPS)
+
     @classmethod
     def convert(cls, module, process_group=None):
         """Replace every BatchNorm / SyncBatchNorm below `module` (in place on the children, like
@@ -373,6 +469,22 @@ class FusedSyncBatchNorm(nn.modules.batchnorm._BatchNorm):
         for name, child in module.named_children():
             out.add_module(name, cls.convert(child, process_group))
         return out
+
+
+def bn_relu_pool(bn, x, pool):
+    """`pool(relu(bn(x)))` of the ResNet stem: one fused pass when `bn` is a FusedSyncBatchNorm in training mode and `pool` is
+    the 3x3 / stride 2 / padding 1 max pooling (the kernels' only shape); the separate ops otherwise."""
+    if (_FUSED_POOL and getattr(bn, "fused", False) and bn.training and bn.track_running_stats and x.is_cuda and x.dim() == 4
+            and isinstance(pool, nn.MaxPool2d) and _pair(pool.kernel_size) == (3, 3) and _pair(pool.stride) == (2, 2)
+            and _pair(pool.padding) == (1, 1) and _pair(pool.dilation) == (1, 1) and not pool.ceil_mode
+            and not pool.return_indices
+            and nv.load().pixpro_bn_pool_supported(x.shape[0] // _VIEW_GROUPS, x.shape[2], x.shape[3], x.shape[1])):
+        return bn.forward_pool(x)
+    return pool(bn_act(bn, x, relu=True))
+
+
+def _pair(v):
+    return (v, v) if isinstance(v, int) else tuple(v)
 
 
 def bn_act(bn, x, relu=False, residual=None, link_out=None, link_in=None):

@@ -64,6 +64,16 @@ int run_corr_lookup(const float* const* levels, int L, const float* coords, floa
 size_t bn_workspace_floats(int64_t M, int C);
 size_t bn_relu_bits_bytes(int64_t M, int C);
 int run_bn_masked_add(const float* a, const float* dy, const void* relu_bits, float* out, int64_t M, int C, hipStream_t st);
+int bn_pool_supported(int N, int H, int W, int C);
+int run_bn_apply_pool(const float* gathered, int Wr, const float* x, const float* weight, const float* bias, float* running_mean,
+                      float* running_var, float momentum, float eps, int N, int H, int W, int C, float* pooled, float* mean,
+                      float* invstd, float* scale_shift, hipStream_t st);
+int run_bn_pool_bwd_reduce(const float* dp, const float* x, const float* scale_shift, const float* mean, const float* invstd,
+                           int N, int H, int W, int C, float* ws, float* sums, float* grad_weight, float* grad_bias,
+                           hipStream_t st);
+int run_bn_pool_bwd_apply(const float* dp, const float* x, const float* scale_shift, const float* mean, const float* invstd,
+                          const float* weight, const float* sums, const float* counts, int world, int64_t count_stride, int N,
+                          int H, int W, int C, float* dx, hipStream_t st);
 int run_bn_stats(const float* x, int64_t M, int C, float* ws, float* packed, hipStream_t st);
 int run_bn_apply(const float* gathered, int W, const float* x, const float* res, const float* weight, const float* bias,
                  float* running_mean, float* running_var, float momentum, float eps, int relu, int64_t M, int C,
@@ -422,6 +432,48 @@ int pixpro_bn_masked_add(const float* a, const float* dy, const void* relu_bits,
   if (!bn_relu_bits_bytes(rows, C)) return bad("batch norm: no ReLU bit record for this shape (pixpro_bn_relu_bits_bytes == 0)");
   if (((uintptr_t)a | (uintptr_t)dy | (uintptr_t)relu_bits | (uintptr_t)out) & 15) return bad("operands must be 16-byte aligned");
   return run_bn_masked_add(a, dy, relu_bits, out, rows, C, (hipStream_t)stream);
+}
+
+int pixpro_bn_pool_supported(int32_t N, int32_t H, int32_t W, int32_t C) {
+  if (N < 1 || H < 1 || W < 1 || C < 4 || (C & 3)) return 0;
+  return bn_pool_supported(N, H, W, C) && pixpro_bn_workspace_bytes((int64_t)N * H * W, C) != 0;
+}
+
+int pixpro_bn_apply_pool(const float* gathered, int32_t world, const float* x, const float* weight, const float* bias,
+                         float* running_mean, float* running_var, float momentum, float eps, int32_t N, int32_t H, int32_t W,
+                         int32_t C, float* pooled, float* mean, float* invstd, float* scale_shift, void* stream) {
+  if (!gathered || !x || !pooled || !mean || !invstd || !scale_shift) return bad("null pointer");
+  if (world < 1) return bad("world must be >= 1");
+  if (!pixpro_bn_pool_supported(N, H, W, C)) return bad("batch norm + pooling: unsupported shape (pixpro_bn_pool_supported == 0)");
+  if (((uintptr_t)x | (uintptr_t)pooled | (uintptr_t)scale_shift) & 15) return bad("x, pooled, scale_shift must be 16-byte aligned");
+  return run_bn_apply_pool(gathered, world, x, weight, bias, running_mean, running_var, momentum, eps, N, H, W, C, pooled, mean,
+                           invstd, scale_shift, (hipStream_t)stream);
+}
+
+int pixpro_bn_pool_backward_reduce(const float* dpooled, const float* x, const float* scale_shift, const float* mean,
+                                   const float* invstd, int32_t N, int32_t H, int32_t W, int32_t C, void* workspace,
+                                   size_t workspace_bytes, float* sums, float* grad_weight, float* grad_bias, void* stream) {
+  if (!dpooled || !x || !scale_shift || !mean || !invstd || !workspace || !sums) return bad("null pointer");
+  if (!pixpro_bn_pool_supported(N, H, W, C)) return bad("batch norm + pooling: unsupported shape (pixpro_bn_pool_supported == 0)");
+  if (workspace_bytes < pixpro_bn_workspace_bytes((int64_t)N * H * W, C)) return bad("workspace too small");
+  if (((uintptr_t)dpooled | (uintptr_t)x | (uintptr_t)scale_shift | (uintptr_t)mean) & 15)
+    return bad("dpooled, x, scale_shift, mean must be 16-byte aligned");
+  return run_bn_pool_bwd_reduce(dpooled, x, scale_shift, mean, invstd, N, H, W, C, (float*)workspace, sums, grad_weight, grad_bias,
+                                (hipStream_t)stream);
+}
+
+int pixpro_bn_pool_backward_apply(const float* dpooled, const float* x, const float* scale_shift, const float* mean,
+                                  const float* invstd, const float* weight, const float* sums, const float* counts,
+                                  int32_t world, int64_t count_stride, int32_t N, int32_t H, int32_t W, int32_t C, float* dx,
+                                  void* stream) {
+  if (!dpooled || !x || !scale_shift || !mean || !invstd || !sums || !dx) return bad("null pointer");
+  if (!counts || world < 1 || count_stride < 1) return bad("counts / world / count_stride: the ranks' row counts are required");
+  if (!pixpro_bn_pool_supported(N, H, W, C)) return bad("batch norm + pooling: unsupported shape (pixpro_bn_pool_supported == 0)");
+  if (((uintptr_t)dpooled | (uintptr_t)x | (uintptr_t)scale_shift | (uintptr_t)mean | (uintptr_t)invstd | (uintptr_t)weight |
+       (uintptr_t)sums | (uintptr_t)dx) & 15)
+    return bad("batch norm backward operands must be 16-byte aligned");
+  return run_bn_pool_bwd_apply(dpooled, x, scale_shift, mean, invstd, weight, sums, counts, world, count_stride, N, H, W, C, dx,
+                               (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -519,6 +519,274 @@ k_masked_add(const float* __restrict__ a, const float* __restrict__ dy, const fl
 #undef USE
 }
 
+// ---- the stem: BatchNorm + ReLU + 3x3 / stride 2 / pad 1 max pooling in one pass (contrast/resnet.py: maxpool(relu(bn1(conv1)))) --
+// The normalised tensor of the stem (822 MB at N = 256) exists only to be pooled: written by k_apply, read by ATen's pooling
+// kernel (which also writes 411 MB of int64 indices), and in backward the pooled gradient is scattered into a full-size
+// tensor that the two BatchNorm backward kernels then read.  Here the forward reads x and writes the pooled tensor; the
+// backward kernels rebuild, per 16 x 16 tile of positions, which position won each window from an LDS tile of x (first
+// maximum in row-major window order, as ATen's index), gather the pooled gradient through that (windows in ascending
+// order: the sum ATen's backward forms), mask it by the ReLU decision and go straight on with the BatchNorm sums / the
+// input gradient.  C % 32 == 0; one work-group = one tile x 32 channels.
+__global__ void __launch_bounds__(BN_TPB)
+k_bn_publish(const float* __restrict__ gathered, int W, const float* __restrict__ weight, const float* __restrict__ bias,
+             float* __restrict__ running_mean, float* __restrict__ running_var, float momentum, float eps,
+             float* __restrict__ mean_out, float* __restrict__ invstd_out, float* __restrict__ scale_shift, int C) {
+  const int c = blockIdx.x * BN_TPB + threadIdx.x;
+  if (c >= C) return;
+  const BnMerged mg = merge_channel(gathered, W, C, c, weight, bias, eps);
+  mean_out[c] = mg.mean;
+  invstd_out[c] = mg.invstd;
+  scale_shift[c] = mg.scale;
+  scale_shift[C + c] = mg.shift;
+  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mg.mean;
+  if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * mg.var_unbiased;
+}
+
+__device__ __forceinline__ float4 bn_relu4(float4 v, float4 sc, float4 sf) {
+  return make_float4(fmaxf(__builtin_fmaf(v.x, sc.x, sf.x), 0.f), fmaxf(__builtin_fmaf(v.y, sc.y, sf.y), 0.f),
+                     fmaxf(__builtin_fmaf(v.z, sc.z, sf.z), 0.f), fmaxf(__builtin_fmaf(v.w, sc.w, sf.w), 0.f));
+}
+
+// forward: one float4 of channels of one pooled pixel per thread slot; a work-group = 8 x 8 pooled pixels x 16 float4
+__global__ void __launch_bounds__(BN_TPB)
+k_apply_pool(const float* __restrict__ x, const float* __restrict__ scale_shift, float* __restrict__ p, int H, int W, int PH,
+             int PW, int C4) {
+  const int c4 = blockIdx.z * 16 + (threadIdx.x & 15);
+  if (c4 >= C4) return;
+  const int n = blockIdx.y;
+  const int tiles_x = (PW + 7) / 8;
+  const int ph0 = (blockIdx.x / tiles_x) * 8, pw0 = (blockIdx.x % tiles_x) * 8;
+  const float4 sc = ld4(scale_shift, c4), sf = ld4(scale_shift + (int64_t)C4 * 4, c4);
+  const float* xn = x + (int64_t)n * H * W * C4 * 4;
+  float* pn = p + (int64_t)n * PH * PW * C4 * 4;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int pix = (threadIdx.x >> 4) + 16 * k;
+    const int ph = ph0 + (pix >> 3), pw = pw0 + (pix & 7);
+    if (ph >= PH || pw >= PW) continue;
+    float4 best = make_float4(0.f, 0.f, 0.f, 0.f);          // every window holds a valid pixel and relu(.) >= 0
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int h = 2 * ph - 1 + kh;
+      if (h < 0 || h >= H) continue;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int w = 2 * pw - 1 + kw;
+        if (w < 0 || w >= W) continue;
+        const float4 y = bn_relu4(ld4(xn, ((int64_t)h * W + w) * C4 + c4), sc, sf);
+        best.x = fmaxf(best.x, y.x); best.y = fmaxf(best.y, y.y); best.z = fmaxf(best.z, y.z); best.w = fmaxf(best.w, y.w);
+      }
+    }
+    st4(pn, ((int64_t)ph * PW + pw) * C4 + c4, best);
+  }
+}
+
+// The gradient that reaches x's position through pooling and ReLU, for the 16 x 16 positions of one tile and 8 float4 of
+// channels: fills `dz[8]` (slot k = position (tid >> 3) + 32 k of the tile) and the matching x values.  LDS: the tile of x
+// with a rim (19 x 19 x 8 float4), the pooled gradient and the winners of the 9 x 9 windows that touch the tile.
+constexpr int PT = 16, PR = PT + 3, PWN = PT / 2 + 1;        // tile positions, x rows/cols held, windows per side
+constexpr int PXL = (PR * PR + BN_TPB / 8 - 1) / (BN_TPB / 8);   // x loads per thread and tile (12)
+constexpr int PDL = (PWN * PWN + BN_TPB / 8 - 1) / (BN_TPB / 8); // pooled-gradient loads per thread and tile (3)
+struct PoolTile {
+  float4 yt[PR][PR][8];
+  float4 dpt[PWN][PWN][8];
+  uchar4 win[PWN][PWN][8];
+};
+struct PoolRegs {
+  float4 xr[PXL], dr[PDL];
+};
+// tile cell of load slot u of thread group g = tid >> 3: slots 0..7 are the group's own interior positions (g + 32 u of the
+// 16 x 16, so that the position phase has its x in registers), slots 8..11 the 105 rim cells in turn
+__device__ __forceinline__ void pool_cell(int g, int u, int& r, int& c, bool& live) {
+  if (u < 8) {
+    const int pos = g + 32 * u;
+    r = 1 + (pos >> 4); c = 1 + (pos & 15); live = true;
+    return;
+  }
+  const int j = g + 32 * (u - 8);
+  live = j < PR * PR - PT * PT;
+  if (j < PR) { r = 0; c = j; }
+  else if (j < 3 * PR) { r = PT + 1 + (j - PR) / PR; c = (j - PR) % PR; }
+  else { const int jj = j - 3 * PR, k3 = jj % 3; r = 1 + jj / 3; c = k3 == 0 ? 0 : PT + k3; }
+}
+// every global load of a tile (x with its rim, the pooled gradient of the windows that touch it) into registers first: one
+// round trip per tile
+__device__ __forceinline__ void pool_tile_load(PoolRegs& R, const float* __restrict__ xn, const float* __restrict__ dpn, int H, int W,
+                                               int PH, int PW, int C4, int cbase, int h0, int w0) {
+  const int tid = threadIdx.x, c8 = tid & 7;
+  const int ph0 = h0 / 2, pw0 = w0 / 2;
+#pragma unroll
+  for (int u = 0; u < PXL; ++u) {
+    int r, c; bool live;
+    pool_cell(tid >> 3, u, r, c, live);
+    const int h = h0 - 1 + r, w = w0 - 1 + c;
+    R.xr[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live && h >= 0 && h < H && w >= 0 && w < W) R.xr[u] = ld4(xn, ((int64_t)h * W + w) * C4 + cbase + c8);
+  }
+#pragma unroll
+  for (int u = 0; u < PDL; ++u) {
+    const int e = (tid >> 3) + u * (BN_TPB / 8);
+    const int wr = e / PWN, wc = e - wr * PWN, ph = ph0 + wr, pw = pw0 + wc;
+    R.dr[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (e < PWN * PWN && ph < PH && pw < PW) R.dr[u] = ld4(dpn, ((int64_t)ph * PW + pw) * C4 + cbase + c8);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+// LDS image of the tile: y = relu(x scale + shift) where the pixel exists, -1 elsewhere (below every y: never a winner)
+__device__ __forceinline__ void pool_tile_commit(PoolTile& T, const PoolRegs& R, int H, int W, int h0, int w0, float4 sc, float4 sf) {
+  const int tid = threadIdx.x, c8 = tid & 7;
+  __syncthreads();                                            // the previous tile's readers are done
+#pragma unroll
+  for (int u = 0; u < PXL; ++u) {
+    int r, c; bool live;
+    pool_cell(tid >> 3, u, r, c, live);
+    const int h = h0 - 1 + r, w = w0 - 1 + c;
+    const bool in = h >= 0 && h < H && w >= 0 && w < W;
+    if (live) T.yt[r][c][c8] = in ? bn_relu4(R.xr[u], sc, sf) : make_float4(-1.f, -1.f, -1.f, -1.f);
+  }
+#pragma unroll
+  for (int u = 0; u < PDL; ++u) {
+    const int e = (tid >> 3) + u * (BN_TPB / 8);
+    if (e < PWN * PWN) T.dpt[e / PWN][e % PWN][c8] = R.dr[u];
+  }
+  __syncthreads();
+}
+// (the tile is in LDS: pool_tile_commit; R still holds the thread's own eight positions in slots 0..7)
+template <class Emit>
+__device__ __forceinline__ void pool_tile_dz(PoolTile& T, const PoolRegs& R, int H, int W, int PH, int PW, int h0, int w0, float4 sc,
+                                             float4 sf, Emit emit) {
+  const int tid = threadIdx.x, c8 = tid & 7;
+  const int ph0 = h0 / 2, pw0 = w0 / 2;                       // first window of the tile (h0, w0 are multiples of 16)
+  for (int e = tid >> 3; e < PWN * PWN; e += BN_TPB / 8) {
+    const int wr = e / PWN, wc = e - wr * PWN;
+    uchar4 id = make_uchar4(255, 255, 255, 255);
+    if (ph0 + wr < PH && pw0 + wc < PW) {
+      float4 best = make_float4(-1.f, -1.f, -1.f, -1.f);     // the first pixel above it wins: first maximum in window order
+#pragma unroll
+      for (int k9 = 0; k9 < 9; ++k9) {
+        const float4 y = T.yt[2 * wr + k9 / 3][2 * wc + k9 % 3][c8];
+        if (y.x > best.x) { best.x = y.x; id.x = (unsigned char)k9; }
+        if (y.y > best.y) { best.y = y.y; id.y = (unsigned char)k9; }
+        if (y.z > best.z) { best.z = y.z; id.z = (unsigned char)k9; }
+        if (y.w > best.w) { best.w = y.w; id.w = (unsigned char)k9; }
+      }
+    }
+    T.win[wr][wc][c8] = id;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int pos = (tid >> 3) + 32 * k, r = pos >> 4, c = pos & 15, h = h0 + r, w = w0 + c;
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (h < H && w < W) {
+      // windows holding (h, w): ph in {h/2} for even h, {(h-1)/2, (h+1)/2} for odd h; likewise pw - taken in ascending
+      // order, as ATen's backward sums them.  A window outside the pooled map carries id 255 and a zero gradient.
+      const int wa = r >> 1, wb = (r + 1) >> 1, va = c >> 1, vb = (c + 1) >> 1;      // local window indices (h0, w0 even)
+      const int kha = r - (2 * wa - 1), khb = r - (2 * wb - 1), kwa = c - (2 * va - 1), kwb = c - (2 * vb - 1);
+      auto take = [&](int wr, int wc, int k9, bool on) {
+        const uchar4 id = T.win[wr][wc][c8];
+        const float4 d = T.dpt[wr][wc][c8];
+        const unsigned char want = on ? (unsigned char)k9 : (unsigned char)254;
+        g.x += id.x == want ? d.x : 0.f; g.y += id.y == want ? d.y : 0.f;
+        g.z += id.z == want ? d.z : 0.f; g.w += id.w == want ? d.w : 0.f;
+      };
+      take(wa, va, kha * 3 + kwa, true);
+      take(wa, vb, kha * 3 + kwb, vb != va);
+      take(wb, va, khb * 3 + kwa, wb != wa);
+      take(wb, vb, khb * 3 + kwb, wb != wa && vb != va);
+      // ReLU: the winner of a window is positive or the whole window is zero (then the gradient stops here)
+      const float4 y = bn_relu4(R.xr[k], sc, sf);
+      g.x = y.x > 0.f ? g.x : 0.f; g.y = y.y > 0.f ? g.y : 0.f; g.z = y.z > 0.f ? g.z : 0.f; g.w = y.w > 0.f ? g.w : 0.f;
+      emit(h, w, g, R.xr[k]);
+    }
+    __builtin_amdgcn_sched_barrier(0);       // one position at a time: the eight unrolled bodies must not pile up their reads
+  }
+}
+
+// partial[by][0][C] = sum dz, partial[by][1][C] = sum dz (x - mean) over the tiles this work-group walks
+__global__ void __launch_bounds__(BN_TPB, 2)
+k_pool_bwd_reduce(const float* __restrict__ dp, const float* __restrict__ x, const float* __restrict__ scale_shift,
+                  const float* __restrict__ mean, float* __restrict__ partial, int N, int H, int W, int PH, int PW, int C4) {
+  __shared__ PoolTile T;
+  __shared__ float4 red[2][BN_TPB];
+  const int c8 = threadIdx.x & 7, cbase = blockIdx.x * 8;
+  const float4 sc = ld4(scale_shift, cbase + c8), sf = ld4(scale_shift + (int64_t)C4 * 4, cbase + c8), mu = ld4(mean, cbase + c8);
+  const int tx = (W + PT - 1) / PT, ty = (H + PT - 1) / PT, per = tx * ty, total = N * per;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = s;
+  PoolRegs R;
+  auto load = [&](int t) {
+    const int n = t / per, tt = t - n * per;
+    pool_tile_load(R, x + (int64_t)n * H * W * C4 * 4, dp + (int64_t)n * PH * PW * C4 * 4, H, W, PH, PW, C4, cbase, (tt / tx) * PT,
+                   (tt % tx) * PT);
+  };
+  for (int t = blockIdx.y; t < total; t += gridDim.y) {
+    const int tt = t % per, h0 = (tt / tx) * PT, w0 = (tt % tx) * PT;
+    load(t);
+    pool_tile_commit(T, R, H, W, h0, w0, sc, sf);
+    pool_tile_dz(T, R, H, W, PH, PW, h0, w0, sc, sf, [&](int, int, float4 g, float4 xo) {
+      s.x += g.x; s.y += g.y; s.z += g.z; s.w += g.w;
+      q.x = __builtin_fmaf(g.x, xo.x - mu.x, q.x); q.y = __builtin_fmaf(g.y, xo.y - mu.y, q.y);
+      q.z = __builtin_fmaf(g.z, xo.z - mu.z, q.z); q.w = __builtin_fmaf(g.w, xo.w - mu.w, q.w);
+    });
+  }
+  red[0][threadIdx.x] = s;
+  red[1][threadIdx.x] = q;
+  __syncthreads();
+  if (threadIdx.x < 8) {                                        // fixed order over the 32 position groups
+    for (int g = 1; g < BN_TPB / 8; ++g) {
+      const float4 u = red[0][g * 8 + c8], v = red[1][g * 8 + c8];
+      s.x += u.x; s.y += u.y; s.z += u.z; s.w += u.w;
+      q.x += v.x; q.y += v.y; q.z += v.z; q.w += v.w;
+    }
+    const int64_t C = (int64_t)C4 * 4;
+    float* pr = partial + (int64_t)blockIdx.y * 2 * C;
+    st4(pr, cbase + c8, s);
+    st4(pr + C, cbase + c8, q);
+  }
+}
+
+// dx = dz a + (x - mean) b + c, as k_bwd_apply
+__global__ void __launch_bounds__(BN_TPB, 2)
+k_pool_bwd_apply(const float* __restrict__ dp, const float* __restrict__ x, const float* __restrict__ scale_shift,
+                 const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ weight,
+                 const float* __restrict__ sums, const float* __restrict__ counts, int Wr, int64_t cstride, float* __restrict__ dx,
+                 int N, int H, int W, int PH, int PW, int C4) {
+  __shared__ PoolTile T;
+  const int c8 = threadIdx.x & 7, cbase = blockIdx.x * 8, cc = cbase + c8;
+  const int64_t C = (int64_t)C4 * 4;
+  const float4 sc = ld4(scale_shift, cc), sf = ld4(scale_shift + C, cc), mu = ld4(mean, cc), is = ld4(invstd, cc);
+  const float4 w = weight ? ld4(weight, cc) : make_float4(1.f, 1.f, 1.f, 1.f);
+  const float4 sd = ld4(sums, cc), sx = ld4(sums + C, cc);
+  double n_all = 0.0;
+  for (int r = 0; r < Wr; ++r) n_all += (double)counts[r * cstride];
+  const float inv_n = (float)(1.0 / n_all);
+  float4 a, b, c;
+  a.x = is.x * w.x; a.y = is.y * w.y; a.z = is.z * w.z; a.w = is.w * w.w;
+  b.x = -(sx.x * inv_n) * is.x * is.x * a.x; b.y = -(sx.y * inv_n) * is.y * is.y * a.y;
+  b.z = -(sx.z * inv_n) * is.z * is.z * a.z; b.w = -(sx.w * inv_n) * is.w * is.w * a.w;
+  c.x = -(sd.x * inv_n) * a.x; c.y = -(sd.y * inv_n) * a.y; c.z = -(sd.z * inv_n) * a.z; c.w = -(sd.w * inv_n) * a.w;
+  const int tx = (W + PT - 1) / PT, ty = (H + PT - 1) / PT, per = tx * ty, total = N * per;
+  PoolRegs R;
+  auto load = [&](int t) {
+    const int n = t / per, tt = t - n * per;
+    pool_tile_load(R, x + (int64_t)n * H * W * C, dp + (int64_t)n * PH * PW * C, H, W, PH, PW, C4, cbase, (tt / tx) * PT, (tt % tx) * PT);
+  };
+  for (int t = blockIdx.y; t < total; t += gridDim.y) {
+    const int n = t / per, tt = t - n * per, h0 = (tt / tx) * PT, w0 = (tt % tx) * PT;
+    load(t);
+    pool_tile_commit(T, R, H, W, h0, w0, sc, sf);
+    float* dxn = dx + (int64_t)n * H * W * C;
+    pool_tile_dz(T, R, H, W, PH, PW, h0, w0, sc, sf, [&](int hh, int ww, float4 g, float4 xo) {
+      float4 o;
+      o.x = __builtin_fmaf(g.x, a.x, __builtin_fmaf(xo.x - mu.x, b.x, c.x));
+      o.y = __builtin_fmaf(g.y, a.y, __builtin_fmaf(xo.y - mu.y, b.y, c.y));
+      o.z = __builtin_fmaf(g.z, a.z, __builtin_fmaf(xo.z - mu.z, b.z, c.z));
+      o.w = __builtin_fmaf(g.w, a.w, __builtin_fmaf(xo.w - mu.w, b.w, c.w));
+      st4(dxn, ((int64_t)hh * W + ww) * C4 + cc, o);
+    });
+  }
+}
+
 #define CHECKED(what)                         \
   do {                                        \
     if (int e = check_launch(what)) return e; \
@@ -651,6 +919,57 @@ int run_bn_masked_add(const float* a, const float* dy, const void* relu_bits, fl
     hipLaunchKernelGGL(k_masked_add<false>, dim3((unsigned)std::max<int64_t>(blocks, 1)), dim3(BN_TPB), 0, st, a, dy,
                        static_cast<const float*>(relu_bits), out, n4);
   CHECKED("k_masked_add");
+  return PIXPRO_OK;
+}
+
+// ---- the stem (BatchNorm + ReLU + 3x3/2 max pooling) ----
+static inline bool pool_shape_ok(int N, int H, int W, int C) {
+  return N >= 1 && H >= 2 && W >= 2 && C >= 32 && C % 32 == 0 && (int64_t)N * ((H + PT - 1) / PT) * ((W + PT - 1) / PT) < 0x7fffffff;
+}
+int bn_pool_supported(int N, int H, int W, int C) { return pool_shape_ok(N, H, W, C); }
+
+int run_bn_apply_pool(const float* gathered, int Wr, const float* x, const float* weight, const float* bias, float* running_mean,
+                      float* running_var, float momentum, float eps, int N, int H, int W, int C, float* pooled, float* mean,
+                      float* invstd, float* scale_shift, hipStream_t st) {
+  if (!pool_shape_ok(N, H, W, C)) return PIXPRO_ERR_ARG;
+  const int PH = (H - 1) / 2 + 1, PW = (W - 1) / 2 + 1;
+  hipLaunchKernelGGL(k_bn_publish, dim3((C + BN_TPB - 1) / BN_TPB), dim3(BN_TPB), 0, st, gathered, Wr, weight, bias, running_mean,
+                     running_var, momentum, eps, mean, invstd, scale_shift, C);
+  CHECKED("k_bn_publish");
+  hipLaunchKernelGGL(k_apply_pool, dim3(((PH + 7) / 8) * ((PW + 7) / 8), N, (C / 4 + 15) / 16), dim3(BN_TPB), 0, st, x,
+                     scale_shift, pooled, H, W, PH, PW, C / 4);
+  CHECKED("k_apply_pool");
+  return PIXPRO_OK;
+}
+
+static inline int pool_rows(int N, int H, int W) {
+  const int64_t tiles = (int64_t)N * ((H + PT - 1) / PT) * ((W + PT - 1) / PT);
+  return (int)std::min<int64_t>(tiles, 1024);
+}
+
+int run_bn_pool_bwd_reduce(const float* dp, const float* x, const float* scale_shift, const float* mean, const float* invstd,
+                           int N, int H, int W, int C, float* ws, float* sums, float* grad_weight, float* grad_bias,
+                           hipStream_t st) {
+  if (!pool_shape_ok(N, H, W, C)) return PIXPRO_ERR_ARG;
+  const int PH = (H - 1) / 2 + 1, PW = (W - 1) / 2 + 1, gy = pool_rows(N, H, W);
+  hipLaunchKernelGGL(k_pool_bwd_reduce, dim3(C / 32, gy), dim3(BN_TPB), 0, st, dp, x, scale_shift, mean, ws + BN_HDR, N, H, W, PH,
+                     PW, C / 4);
+  CHECKED("k_pool_bwd_reduce");
+  hipLaunchKernelGGL(k_bwd_finalize, dim3((C + FIN_CH - 1) / FIN_CH), dim3(BN_TPB), 0, st, ws + BN_HDR, gy, C, invstd, sums,
+                     grad_weight, grad_bias);
+  CHECKED("k_bwd_finalize");
+  return PIXPRO_OK;
+}
+
+int run_bn_pool_bwd_apply(const float* dp, const float* x, const float* scale_shift, const float* mean, const float* invstd,
+                          const float* weight, const float* sums, const float* counts, int world, int64_t count_stride, int N,
+                          int H, int W, int C, float* dx, hipStream_t st) {
+  if (!pool_shape_ok(N, H, W, C)) return PIXPRO_ERR_ARG;
+  const int PH = (H - 1) / 2 + 1, PW = (W - 1) / 2 + 1;
+  const int64_t tiles = (int64_t)N * ((H + PT - 1) / PT) * ((W + PT - 1) / PT);
+  hipLaunchKernelGGL(k_pool_bwd_apply, dim3(C / 32, (unsigned)std::min<int64_t>(tiles, 1024)), dim3(BN_TPB), 0, st, dp, x,
+                     scale_shift, mean, invstd, weight, sums, counts, world, count_stride, dx, N, H, W, PH, PW, C / 4);
+  CHECKED("k_pool_bwd_apply");
   return PIXPRO_OK;
 }
 

@@ -593,3 +593,56 @@ def test_shortcut_gradient_over_the_link_in_the_encoders(dev, arch, groups, monk
         assert got <= 4 * noise + 1e-5, (n, got, noise)
     # the comparison must say something: on the big tensors the noise is small
     assert rel_err(out["plain2"][0], out["plain"][0]) < 1e-2 and rel_err(out["plain2"][1], out["plain"][1]) < 5e-2, sorted(worst)[-3:]
+
+
+@pytest.mark.parametrize("shape,groups", [((4, 64, 112, 112), 1), ((3, 64, 30, 42), 1), ((2, 32, 17, 9), 2), ((2, 128, 16, 16), 1),
+                                          ((1, 64, 2, 3), 1)])
+@pytest.mark.parametrize("ties", [False, True])
+def test_stem_bn_relu_maxpool_in_one_pass(dev, shape, groups, ties, monkeypatch):
+    """bn_relu_pool: BatchNorm + ReLU + 3x3/2/1 max pooling without the full-resolution tensor in between, against the same
+    FusedSyncBatchNorm followed by ATen's pooling.  The pooled output is bit-identical; the input gradient and the
+    BatchNorm gradients agree to the re-association of the channel sums (the gathered pooled gradient itself is summed in
+    ATen's order).  `ties`: inputs on a coarse grid, so that windows hold equal maxima and the first-maximum rule decides."""
+    from contrast import sync_bn, _native
+    from contrast.sync_bn import FusedSyncBatchNorm, bn_relu_pool, view_groups
+    N, C, H, W = shape
+    N *= groups
+    g = torch.Generator().manual_seed(sum(shape) + groups + 7 * ties)
+    x = torch.randn(N, C, H, W, generator=g) * 1.5 + 0.2
+    if ties:
+        x = torch.round(x * 2) / 2
+    x = x.to(dev).contiguous(memory_format=CL)
+    pool = nn.MaxPool2d(3, stride=2, padding=1)
+    assert _native.load().pixpro_bn_pool_supported(N // groups, H, W, C) == 1
+    out = {}
+    dy = None
+    real = _native.call
+    for fused in (True, False):
+        monkeypatch.setattr(sync_bn, "_FUSED_POOL", fused)
+        calls = []
+        monkeypatch.setattr(_native, "call", lambda name, *a: (calls.append(name), real(name, *a))[1])
+        bn = FusedSyncBatchNorm(C).to(dev).train()
+        with torch.no_grad():
+            bn.weight.copy_(torch.linspace(0.5, 1.5, C))
+            bn.bias.copy_(torch.linspace(-0.3, 0.3, C))
+        xf = x.clone().requires_grad_(True)
+        with view_groups(groups):
+            y = bn_relu_pool(bn, xf, pool)
+        if dy is None:
+            dy = torch.randn(y.shape, generator=g).to(dev).contiguous(memory_format=CL)
+        y.backward(dy)
+        monkeypatch.setattr(_native, "call", real)
+        assert ("pixpro_bn_apply_pool" in calls) == fused and ("pixpro_bn_pool_backward_apply" in calls) == fused
+        out[fused] = (y.detach(), xf.grad, bn.weight.grad, bn.bias.grad, bn.running_mean.clone(), bn.running_var.clone(),
+                      int(bn.num_batches_tracked))
+    assert out[True][0].shape == (N, C, (H - 1) // 2 + 1, (W - 1) // 2 + 1)
+    assert torch.equal(out[True][0], out[False][0])
+    close(out[True][1], out[False][1], rel=2e-5)
+    close(out[True][2], out[False][2], rel=2e-4)
+    close(out[True][3], out[False][3], rel=2e-4)
+    assert torch.equal(out[True][4], out[False][4]) and torch.equal(out[True][5], out[False][5]) and out[True][6] == out[False][6]
+    # the key encoder's passes (no gradient) take the fused forward as well
+    monkeypatch.setattr(sync_bn, "_FUSED_POOL", True)
+    with torch.no_grad(), view_groups(groups):
+        y2 = bn_relu_pool(FusedSyncBatchNorm(C).to(dev).train(), x, pool)
+    assert y2.shape == out[True][0].shape
