@@ -892,9 +892,10 @@ def main():
     extra = None
     if rank == 0 and world == 1 and not a.no_extra_configs and (a.image_size, a.n_frames) == (224, 2) and a.arch == "resnet50":
         extra = {}
-        for name, size_, nf_, nb_ in (("configs[3] per-GPU share: nframe=6, global batch 512 over 8 GPUs", 224, 6, 64),
+        for name, size_, nf_, nb_ in (("configs[2] per-GPU share: nframe=2, global batch 1024 over 8 GPUs", 224, 2, 128),
+                                      ("configs[3] per-GPU share: nframe=6, global batch 512 over 8 GPUs", 224, 6, 64),
                                       ("configs[4] per-GPU share: 448x448 crops (14x14 grid), N=64", 448, 2, 64)):
-            key = f"nframe{nf_}_n{nb_}" if nf_ != 2 else f"crop{size_}_n{nb_}"
+            key = f"nframe{nf_}_n{nb_}" if (nf_, size_) != (2, 448) else f"crop{size_}_n{nb_}"
             try:
                 extra[key] = extra_config_leg(a, name, size_, nf_, nb_, model, optimizer, scheduler, args, clock, dev, rank)
             except Exception as exc:      # never lose the headline line to an extra leg
