@@ -11,6 +11,13 @@ the streaming kernels of csrc/sync_bn.hip:
     y = relu?( batch_norm(x) (+ residual) )                    3 (4) tensor passes instead of 5 (8)
     backward: dz = dy * (y > 0)?; dx, dweight, dbias, dresidual = dz
 
+Three things keep traffic out of the backward pass (round 4): behind a residual add the ReLU decisions are
+kept as a bit record instead of being read back from the saved output (`pixpro_bn_apply_bits`); the shortcut gradient of a
+residual unit is handed to its consumer as (dy, bits) over a `ResidualLink` instead of being written and added by
+autograd (`fork`, `link_in` / `link_out`); and the stem's `maxpool(relu(bn1(x)))` is one pass in each direction
+(`bn_relu_pool`).  All three are bit-compatible with the plain route and have an environment switch for A/B runs
+(PIXPRO_BN_RELU_BITS, PIXPRO_BN_LAZY_SHORTCUT, PIXPRO_BN_FUSED_POOL = 0).
+
 Parameter / buffer names are those of `nn.BatchNorm2d` (`weight, bias, running_mean, running_var, num_batches_tracked`),
 so checkpoints load either way.  Activations must be channels_last (the layout the encoders run in); CPU tensors raise.
 """
