@@ -99,7 +99,8 @@ __device__ __forceinline__ void st4nt(float* p, int64_t i4, float4 v) {
 #define LDX(NT, p, i) ((NT) ? ld4nt(p, i) : ld4(p, i))
 struct BnStream { bool stats, apply, bwd_reduce, bwd_apply; };
 inline BnStream bn_stream_policy(int64_t M, int C, bool writes_dres) {
-  static const int mode = [] { const char* e = getenv("PIXPRO_BN_STREAM"); return e ? atoi(e) : -1; }();   // 0 / 1 force, tests
+  const char* env = getenv("PIXPRO_BN_STREAM");                // 0 / 1 force the choice (read per call: tests switch it)
+  const int mode = env && env[0] ? atoi(env) : -1;
   if (mode == 0) return BnStream{false, false, false, false};
   if (mode == 1) return BnStream{true, true, true, true};
   const double mb = (double)M * C * 4 / 1e6;

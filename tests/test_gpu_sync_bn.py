@@ -646,3 +646,32 @@ def test_stem_bn_relu_maxpool_in_one_pass(dev, shape, groups, ties, monkeypatch)
     with torch.no_grad(), view_groups(groups):
         y2 = bn_relu_pool(FusedSyncBatchNorm(C).to(dev).train(), x, pool)
     assert y2.shape == out[True][0].shape
+
+
+@pytest.mark.parametrize("shape,relu,with_res", [((6, 256, 14, 14), True, True), ((5, 64, 28, 28), True, False),
+                                                 ((4, 512, 7, 7), False, False), ((3, 1024, 5, 9), True, True)])
+def test_streaming_load_kernels_are_bit_identical(dev, shape, relu, with_res, monkeypatch):
+    """bn_stream_policy picks the non-temporal-load instantiations only for tensors of tens of MB, which no other test
+    reaches: PIXPRO_BN_STREAM=1 forces them here (0 forces the plain ones).  A load is a load: forward, every gradient and
+    the running statistics must be the same bits, through the bit record and the shortcut link as well."""
+    from contrast.sync_bn import FusedSyncBatchNorm, bn_act, fork, residual_link
+    N, C, H, W = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = (torch.randn(shape, generator=g) * 1.4 + 0.1).to(dev).contiguous(memory_format=CL)
+    dy = torch.randn(shape, generator=g).to(dev).contiguous(memory_format=CL)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("PIXPRO_BN_STREAM", mode)
+        bn_a, bn_b = FusedSyncBatchNorm(C).to(dev).train(), FusedSyncBatchNorm(C).to(dev).train()
+        xf = x.clone().requires_grad_(True)
+        if with_res:                       # a unit: fork -> bn_a + relu -> bn_b + shortcut + relu, gradient over the link
+            link = residual_link(xf, bn_b)
+            xa, identity = fork(xf, link) if link is not None else (xf, xf)
+            y = bn_act(bn_b, bn_act(bn_a, xa * 1.5, relu=True), relu=True, residual=identity, link_out=link)
+        else:
+            y = bn_act(bn_b, bn_act(bn_a, xf * 1.5, relu=relu), relu=relu)
+        y.backward(dy)
+        out[mode] = [y.detach(), xf.grad, bn_a.weight.grad, bn_a.bias.grad, bn_b.weight.grad, bn_b.bias.grad,
+                     bn_a.running_var.clone(), bn_b.running_mean.clone()]
+    for a, b in zip(out["1"], out["0"]):
+        assert torch.equal(a, b)
