@@ -610,12 +610,20 @@ struct PoolTile {
 struct PoolRegs {
   float4 xr[PXL], dr[PDL];
 };
-// tile cell of load slot u of thread group g = tid >> 3: slots 0..7 are the group's own interior positions (g + 32 u of the
-// 16 x 16, so that the position phase has its x in registers), slots 8..11 the 105 rim cells in turn
+// Position (row, column in 0..15) of slot k of thread group g = tid >> 3.  The 256 positions of a tile are dealt by PARITY
+// CLASS: slots 2c, 2c + 1 hold the 64 positions with (row & 1, column & 1) = (c >> 1, c & 1), so that in the unrolled
+// position loop the number of windows a position belongs to (1, 2, 2 or 4) is a compile-time fact of the slot.
+__device__ __forceinline__ void pool_pos(int g, int k, int& r, int& c) {
+  const int idx = g + 32 * (k & 1), cls = k >> 1;
+  r = 2 * (idx >> 3) + (cls >> 1);
+  c = 2 * (idx & 7) + (cls & 1);
+}
+// tile cell of load slot u of thread group g: slots 0..7 are the group's own interior positions (pool_pos: the position
+// phase then has its x in registers), slots 8..11 the 105 rim cells in turn
 __device__ __forceinline__ void pool_cell(int g, int u, int& r, int& c, bool& live) {
   if (u < 8) {
-    const int pos = g + 32 * u;
-    r = 1 + (pos >> 4); c = 1 + (pos & 15); live = true;
+    pool_pos(g, u, r, c);
+    r += 1; c += 1; live = true;
     return;
   }
   const int j = g + 32 * (u - 8);
@@ -691,7 +699,9 @@ __device__ __forceinline__ void pool_tile_dz(PoolTile& T, const PoolRegs& R, int
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    const int pos = (tid >> 3) + 32 * k, r = pos >> 4, c = pos & 15, h = h0 + r, w = w0 + c;
+    int r, c;
+    pool_pos(tid >> 3, k, r, c);
+    const int h = h0 + r, w = w0 + c;
     float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
     if (h < H && w < W) {
       // windows holding (h, w): ph in {h/2} for even h, {(h-1)/2, (h+1)/2} for odd h; likewise pw - taken in ascending
@@ -705,10 +715,12 @@ __device__ __forceinline__ void pool_tile_dz(PoolTile& T, const PoolRegs& R, int
         g.x += id.x == want ? d.x : 0.f; g.y += id.y == want ? d.y : 0.f;
         g.z += id.z == want ? d.z : 0.f; g.w += id.w == want ? d.w : 0.f;
       };
+      // (row odd <=> two window rows, column odd <=> two window columns: known per slot, the absent ones compile away)
+      const bool two_r = ((k >> 1) >> 1) != 0, two_c = ((k >> 1) & 1) != 0;
       take(wa, va, kha * 3 + kwa, true);
-      take(wa, vb, kha * 3 + kwb, vb != va);
-      take(wb, va, khb * 3 + kwa, wb != wa);
-      take(wb, vb, khb * 3 + kwb, wb != wa && vb != va);
+      if (two_c) take(wa, vb, kha * 3 + kwb, true);
+      if (two_r) take(wb, va, khb * 3 + kwa, true);
+      if (two_r && two_c) take(wb, vb, khb * 3 + kwb, true);
       // ReLU: the winner of a window is positive or the whole window is zero (then the gradient stops here)
       const float4 y = bn_relu4(R.xr[k], sc, sf);
       g.x = y.x > 0.f ? g.x : 0.f; g.y = y.y > 0.f ? g.y : 0.f; g.z = y.z > 0.f ? g.z : 0.f; g.w = y.w > 0.f ? g.w : 0.f;
