@@ -155,6 +155,37 @@ def _part(t, g, G):
     return t.narrow(0, g * n, n)
 
 
+def _statistics(x, rows, C, G, group):
+    """Local statistics of the G views of x (pixpro_bn_stats) and their exchange: returns (small, gathered, world) - `small`
+    is the one allocation behind the per-layer records (its tail holds mean / invstd / scale_shift), `gathered[g]` the
+    [world, 2C+1] records of view g as the apply kernels read them."""
+    dev = x.device
+    f32 = dict(dtype=torch.float32, device=dev)
+    wsb = nv.load().pixpro_bn_workspace_bytes(rows, C)
+    if wsb == 0:
+        raise RuntimeError(f"FusedSyncBatchNorm: unsupported shape rows={rows}, C={C} (C must be a multiple of 4)")
+    ws = nv.zeroed_workspace(wsb, dev)            # tickets + partial sums: one buffer per stream, reused by every layer
+    # one allocation for the four small per-layer records (16-B aligned pieces: C % 4 == 0)
+    small = torch.empty(G * (2 * C + 4) + G * 4 * C, **f32)
+    packed = small[:G * (2 * C + 1)].view(G, 2 * C + 1)
+    for g in range(G):
+        nv.call("pixpro_bn_stats", nv.ptr(_part(x, g, G)), rows, C, nv.ptr(ws), wsb, nv.ptr(packed[g]), nv.stream())
+    world = _world(group)
+    if world > 1:
+        gathered = torch.empty(world, G, 2 * C + 1, **f32)
+        if dist.get_backend(group) == "gloo":      # rehearsal / tests: no all_gather_into_tensor on gloo
+            parts = list(gathered.unbind(0))
+            dist.all_gather(parts, packed, group=group)
+            gathered = torch.stack(parts)
+        else:
+            dist.all_gather_into_tensor(gathered, packed, group=group)
+        # the kernels read one view's records as [world, 2C+1]
+        gathered = gathered.transpose(0, 1).contiguous() if G > 1 else gathered.reshape(1, world, 2 * C + 1)
+    else:
+        gathered = packed.reshape(G, 1, 2 * C + 1)
+    return small, gathered, world
+
+
 class _FusedBN(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, residual, running_mean, running_var, momentum, eps, relu, group, G, grad_mode=True,
@@ -170,29 +201,7 @@ class _FusedBN(torch.autograd.Function):
             raise RuntimeError(f"view_groups({G}): batch {x.shape[0]} is not a multiple of the number of views")
         rows //= G
         dev = x.device
-        f32 = dict(dtype=torch.float32, device=dev)
-        wsb = nv.load().pixpro_bn_workspace_bytes(rows, C)
-        if wsb == 0:
-            raise RuntimeError(f"FusedSyncBatchNorm: unsupported shape rows={rows}, C={C} (C must be a multiple of 4)")
-        ws = nv.zeroed_workspace(wsb, dev)            # tickets + partial sums: one buffer per stream, reused by every layer
-        # one allocation for the four small per-layer records (16-B aligned pieces: C % 4 == 0)
-        small = torch.empty(G * (2 * C + 4) + G * 4 * C, **f32)
-        packed = small[:G * (2 * C + 1)].view(G, 2 * C + 1)
-        for g in range(G):
-            nv.call("pixpro_bn_stats", nv.ptr(_part(x, g, G)), rows, C, nv.ptr(ws), wsb, nv.ptr(packed[g]), nv.stream())
-        world = _world(group)
-        if world > 1:
-            gathered = torch.empty(world, G, 2 * C + 1, **f32)
-            if dist.get_backend(group) == "gloo":      # rehearsal / tests: no all_gather_into_tensor on gloo
-                parts = list(gathered.unbind(0))
-                dist.all_gather(parts, packed, group=group)
-                gathered = torch.stack(parts)
-            else:
-                dist.all_gather_into_tensor(gathered, packed, group=group)
-            # the kernels read one view's records as [world, 2C+1]
-            gathered = gathered.transpose(0, 1).contiguous() if G > 1 else gathered.reshape(1, world, 2 * C + 1)
-        else:
-            gathered = packed.reshape(G, 1, 2 * C + 1)
+        small, gathered, world = _statistics(x, rows, C, G, group)
         y = torch.empty_like(x)
         rest = small[G * (2 * C + 4):]
         mean, invstd, scale_shift = rest[:G * C].view(G, C), rest[G * C:2 * G * C].view(G, C), rest[2 * G * C:].view(G, 2 * C)
@@ -312,29 +321,9 @@ class _FusedBNPool(torch.autograd.Function):
         if N % G:
             raise RuntimeError(f"view_groups({G}): batch {N} is not a multiple of the number of views")
         Nv, rows = N // G, rows // G
-        dev = x.device
-        f32 = dict(dtype=torch.float32, device=dev)
-        lib = nv.load()
-        wsb = lib.pixpro_bn_workspace_bytes(rows, C)
-        ws = nv.zeroed_workspace(wsb, dev)
-        small = torch.empty(G * (2 * C + 4) + G * 4 * C, **f32)
-        packed = small[:G * (2 * C + 1)].view(G, 2 * C + 1)
-        for g in range(G):
-            nv.call("pixpro_bn_stats", nv.ptr(_part(x, g, G)), rows, C, nv.ptr(ws), wsb, nv.ptr(packed[g]), nv.stream())
-        world = _world(group)
-        if world > 1:
-            gathered = torch.empty(world, G, 2 * C + 1, **f32)
-            if dist.get_backend(group) == "gloo":
-                parts = list(gathered.unbind(0))
-                dist.all_gather(parts, packed, group=group)
-                gathered = torch.stack(parts)
-            else:
-                dist.all_gather_into_tensor(gathered, packed, group=group)
-            gathered = gathered.transpose(0, 1).contiguous() if G > 1 else gathered.reshape(1, world, 2 * C + 1)
-        else:
-            gathered = packed.reshape(G, 1, 2 * C + 1)
+        small, gathered, world = _statistics(x, rows, C, G, group)
         PH, PW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
-        pooled = torch.empty((N, C, PH, PW), **f32).contiguous(memory_format=torch.channels_last)
+        pooled = torch.empty((N, C, PH, PW), dtype=torch.float32, device=x.device).contiguous(memory_format=torch.channels_last)
         rest = small[G * (2 * C + 4):]
         mean, invstd, scale_shift = rest[:G * C].view(G, C), rest[G * C:2 * G * C].view(G, C), rest[2 * G * C:].view(G, 2 * C)
         for g in range(G):
