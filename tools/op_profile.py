@@ -37,7 +37,7 @@ def main():
     for _ in range(2):
         main_pretrain.train_step(model, optimizer, scheduler, next(it), args)
     torch.cuda.synchronize()
-    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
         main_pretrain.train_step(model, optimizer, scheduler, next(it), args)
         torch.cuda.synchronize()
     ev = prof.events()
@@ -47,14 +47,16 @@ def main():
         if e.device_type.name != "CPU" or not e.kernels:
             continue
         for k in e.kernels:
-            key = (k.name[:70], e.name)
+            # (shapes only for the plain copies / adds: which tensors are they?)
+            shp = str(e.input_shapes)[:60] if e.name in ("aten::copy_", "aten::add_", "aten::add") and k.duration > 20 else ""
+            key = (k.name[:70], e.name + " " + shp)
             rows[key][0] += 1
             rows[key][1] += k.duration
     small = sorted(rows.items(), key=lambda kv: -kv[1][1])
     for (kn, op), (n, us) in small[:60]:
         if "igemm" in kn or "Cijk" in kn or "k_stats" in kn or "k_apply" in kn or "k_bwd" in kn:
             continue
-        print(f"{us / 1e3:8.3f} ms  calls {n:4d}  {op:45s} {kn}")
+        print(f"{us / 1e3:8.3f} ms  calls {n:4d}  {op:75s} {kn}")
 
 
 if __name__ == "__main__":
