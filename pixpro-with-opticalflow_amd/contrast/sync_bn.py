@@ -323,7 +323,7 @@ class _FusedBNPool(torch.autograd.Function):
         Nv, rows = N // G, rows // G
         small, gathered, world = _statistics(x, rows, C, G, group)
         PH, PW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
-        pooled = torch.empty((N, C, PH, PW), dtype=torch.float32, device=x.device).contiguous(memory_format=torch.channels_last)
+        pooled = torch.empty((N, C, PH, PW), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
         rest = small[G * (2 * C + 4):]
         mean, invstd, scale_shift = rest[:G * C].view(G, C), rest[G * C:2 * G * C].view(G, C), rest[2 * G * C:].view(G, 2 * C)
         for g in range(G):
