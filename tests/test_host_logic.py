@@ -344,3 +344,39 @@ def test_bench_line_helpers():
     a5 = types.SimpleNamespace(image_size=448, n_frames=2, batch=64, arch="resnet50", overlap_momentum=True)
     k5 = b.hot_kernel_lines(a5, {"ppm_loss": 0.296})
     assert k5["ppm_loss"]["algorithmic_flops_per_launch"] == 24 * 256 * 196 * 196 * 64 and "attainable" not in k5["ppm_loss"]
+
+
+def test_residual_units_and_stem_keep_the_stock_route_without_the_fused_modules():
+    """The traffic-saving routes of contrast/sync_bn.py (ReLU bit record, ResidualLink, fused stem) exist for
+    FusedSyncBatchNorm on the GPU only: with stock BatchNorm on the CPU `residual_link` hands out no link, `bn_relu_pool`
+    is pool(relu(bn(x))), and the encoder's forward / backward are those of the plain ops."""
+    import torch
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from contrast import resnet
+    from contrast.sync_bn import bn_relu_pool, residual_link
+    torch.manual_seed(0)
+    bn, pool = nn.BatchNorm2d(8).train(), nn.MaxPool2d(3, stride=2, padding=1)
+    x = torch.randn(2, 8, 9, 11, requires_grad=True)
+    assert residual_link(x, bn) is None
+    want = pool(F.relu(nn.BatchNorm2d(8).train()(x)))
+    assert torch.equal(bn_relu_pool(bn, x, pool), want)
+    net = resnet.resnet18(head_type="early_return").train()
+    y = net(torch.randn(2, 3, 64, 64))
+    y.sum().backward()
+    assert y.shape == (2, 512, 2, 2) and all(p.grad is not None for p in net.parameters())
+
+
+def test_lars_zero_grad_releases_the_gradients():
+    """LARS.zero_grad() sets gradients to None (torch's default since 2.0; contrast/lars.py says why) and still honours
+    set_to_none=False."""
+    import torch
+    from contrast.lars import LARS
+    p = torch.nn.Parameter(torch.ones(3, 3))
+    opt = LARS([{"params": [p], "weight_decay": 0.0, "ignore": False}], lr=0.1, momentum=0.9)
+    p.grad = torch.ones_like(p)
+    opt.zero_grad()
+    assert p.grad is None
+    p.grad = torch.ones_like(p)
+    opt.zero_grad(set_to_none=False)
+    assert p.grad is not None and float(p.grad.abs().sum()) == 0.0
