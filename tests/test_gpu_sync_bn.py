@@ -675,3 +675,55 @@ def test_streaming_load_kernels_are_bit_identical(dev, shape, relu, with_res, mo
                      bn_a.running_var.clone(), bn_b.running_mean.clone()]
     for a, b in zip(out["1"], out["0"]):
         assert torch.equal(a, b)
+
+
+def _rank_pool(rank, world, port, path):
+    for p in (ROOT, PKG):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from contrast.sync_bn import FusedSyncBatchNorm, bn_relu_pool
+    dev = torch.device("cuda:0")
+    d = torch.load(path)
+    sl = slice(0, 5) if rank == 0 else slice(5, d["x"].shape[0])      # unequal shards: 5 and 3 samples
+    bn = FusedSyncBatchNorm(d["x"].shape[1]).to(dev).train()
+    with torch.no_grad():
+        bn.weight.copy_(d["w"]); bn.bias.copy_(d["b"])
+    x = d["x"][sl].to(dev).contiguous(memory_format=CL).requires_grad_(True)
+    y = bn_relu_pool(bn, x, nn.MaxPool2d(3, stride=2, padding=1))
+    y.backward(d["dy"][sl].to(dev).contiguous(memory_format=CL))
+    torch.save(dict(y=y.detach().cpu(), dx=x.grad.cpu(), dw=bn.weight.grad.cpu(), db=bn.bias.grad.cpu(),
+                    rm=bn.running_mean.cpu(), rv=bn.running_var.cpu()), f"{path}.out{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_fused_stem_over_two_ranks_equals_one_process_on_the_whole_batch(dev, tmp_path):
+    """The fused BatchNorm + ReLU + max pooling of the stem under the SyncBN contract: two ranks with unequal shards give
+    the pooled output, the input gradient and the running statistics of one process on the whole batch; parameter
+    gradients are the local sums."""
+    from contrast.sync_bn import FusedSyncBatchNorm, bn_relu_pool
+    g = torch.Generator().manual_seed(23)
+    shape, C = (8, 64, 20, 18), 64
+    d = dict(x=torch.randn(shape, generator=g) * 1.5 + 0.3, dy=torch.randn(8, C, 10, 9, generator=g),
+             w=torch.rand(C, generator=g) + 0.5, b=torch.randn(C, generator=g) * 0.3)
+    d["x"][5:] += 0.6
+    path = str(tmp_path / "pool.pt")
+    torch.save(d, path)
+    mp.spawn(_rank_pool, args=(2, _free_port(), path), nprocs=2, join=True)
+    outs = [torch.load(f"{path}.out{r}") for r in range(2)]
+    bn = FusedSyncBatchNorm(C).to(dev).train()
+    with torch.no_grad():
+        bn.weight.copy_(d["w"]); bn.bias.copy_(d["b"])
+    x = d["x"].to(dev).contiguous(memory_format=CL).requires_grad_(True)
+    y = bn_relu_pool(bn, x, nn.MaxPool2d(3, stride=2, padding=1))
+    y.backward(d["dy"].to(dev).contiguous(memory_format=CL))
+    got_y = torch.cat([o["y"] for o in outs]).to(dev)
+    assert (got_y - y).abs().max().item() <= 2e-5
+    # (the statistics are the global ones on both sides; what differs is the order of their sums)
+    close(torch.cat([o["dx"] for o in outs]).to(dev), x.grad, rel=2e-3)
+    close(outs[0]["dw"] + outs[1]["dw"], bn.weight.grad, rel=1e-3)
+    close(outs[0]["db"] + outs[1]["db"], bn.bias.grad, rel=1e-3)
+    for o in outs:
+        assert torch.allclose(o["rm"].to(dev), bn.running_mean, rtol=1e-5, atol=1e-6)
+        assert torch.allclose(o["rv"].to(dev), bn.running_var, rtol=1e-5, atol=1e-6)
